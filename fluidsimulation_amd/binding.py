@@ -1,0 +1,352 @@
+"""ctypes mirror of include/pbf.h and loader of the HIP extension (libpbf_hip.so).
+
+Plumbing only: the product is the C-ABI library.  There is NO CPU fallback here --
+if the extension is missing or no GPU is usable, the calls raise (PbfError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PBF_ABI_VERSION = 1
+PBF_MAX_COLLIDERS = 16
+
+PBF_OK = 0
+PBF_ERR_INVALID = 1
+PBF_ERR_HIP = 2
+PBF_ERR_CAPACITY = 3
+PBF_ERR_NEIGHBOR_OVERFLOW = 4
+PBF_ERR_NO_DEVICE = 5
+PBF_ERR_NOT_INITIALIZED = 6
+
+PBF_COLLIDER_AABB = 2   # Collider::ColliderTypes::AABB  (reference Collider.h:10-17)
+PBF_COLLIDER_PLANE = 4  # Collider::ColliderTypes::PLANE
+
+PBF_RHO0_FIRST_FRAME_MEAN = 0
+PBF_RHO0_FIXED = 1
+PBF_ARITH_STRICT = 0
+PBF_ARITH_FAST = 1
+PBF_GRAD_POLY6 = 0
+PBF_GRAD_SPIKY = 1
+
+
+class PbfCollider(C.Structure):
+    _fields_ = [("type", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("d", C.c_float)]
+
+
+class PbfParams(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("capacity", C.c_uint32),
+        ("max_neighbors", C.c_uint32),
+        ("grid_dim", C.c_int32 * 3),
+        ("grid_spacing", C.c_float),
+        ("effective_radius", C.c_float),
+        ("gravity", C.c_float * 3),
+        ("epsilon", C.c_float),
+        ("restitution", C.c_float),
+        ("scorr_k", C.c_double),
+        ("scorr_dq", C.c_float),
+        ("scorr_dt_power", C.c_int32),
+        ("rest_density_mode", C.c_int32),
+        ("rest_density", C.c_float),
+        ("solver_iterations", C.c_int32),
+        ("arithmetic", C.c_int32),
+        ("gradient_kernel", C.c_int32),
+        ("container_enabled", C.c_int32),
+        ("container_min", C.c_float * 3),
+        ("container_max", C.c_float * 3),
+        ("xsph_c", C.c_float),
+        ("vorticity_eps", C.c_float),
+    ]
+
+    def copy(self) -> "PbfParams":
+        q = PbfParams()
+        C.memmove(C.byref(q), C.byref(self), C.sizeof(PbfParams))
+        return q
+
+
+class PbfStats(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("nonfinite", C.c_uint32),
+        ("neighbor_overflow", C.c_uint32),
+        ("max_neighbor_count", C.c_uint32),
+        ("mean_neighbor_count", C.c_double),
+        ("mean_abs_C", C.c_double),
+        ("max_abs_C", C.c_double),
+        ("mean_C", C.c_double),
+        ("com", C.c_double * 3),
+        ("max_speed", C.c_double),
+        ("rest_density", C.c_float),
+    ]
+
+    def as_dict(self) -> dict:
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+def default_params() -> PbfParams:
+    """The reference CPU path's constants (mirror of pbf_default_params)."""
+    p = PbfParams()
+    p.abi_version = PBF_ABI_VERSION
+    p.capacity = 0
+    p.max_neighbors = 64
+    p.grid_dim[:] = [64, 64, 64]          # Simulation.cpp:46
+    p.grid_spacing = 1.0                  # NeighborSearch.cpp:17
+    p.effective_radius = 1.0              # Simulation.cpp:88
+    p.gravity[:] = [0.0, -9.8, 0.0]       # Simulation.cpp:16
+    p.epsilon = 1.0e-6                    # Simulation.cpp:644
+    p.restitution = 0.99                  # Particle.cpp:333
+    p.scorr_k = 0.1                       # Simulation.cpp:698
+    p.scorr_dq = 0.3                      # Simulation.cpp:700
+    p.scorr_dt_power = 1                  # Simulation.cpp:702
+    p.rest_density_mode = PBF_RHO0_FIRST_FRAME_MEAN
+    p.rest_density = 0.8                  # Simulation.cpp:18
+    p.solver_iterations = 1               # ConstraintSolver.cpp:4
+    p.arithmetic = PBF_ARITH_STRICT
+    p.gradient_kernel = PBF_GRAD_POLY6
+    return p
+
+
+def plane(normal, d) -> PbfCollider:
+    c = PbfCollider()
+    c.type = PBF_COLLIDER_PLANE
+    c.a[:] = [float(x) for x in normal]
+    c.d = float(d)
+    return c
+
+
+def aabb(mn, mx) -> PbfCollider:
+    c = PbfCollider()
+    c.type = PBF_COLLIDER_AABB
+    c.a[:] = [float(x) for x in mn]
+    c.b[:] = [float(x) for x in mx]
+    return c
+
+
+def collider_array(cols):
+    arr = (PbfCollider * max(1, len(cols)))()
+    for i, c in enumerate(cols):
+        arr[i] = c
+    return arr
+
+
+class PbfError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pbf error {code}: {msg}")
+        self.code = code
+
+
+_REPO = Path(__file__).resolve().parent.parent
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libpbf_hip.so"
+
+# every symbol include/pbf.h declares
+SYMBOLS = [
+    "pbf_default_params", "pbf_create", "pbf_destroy", "pbf_last_error", "pbf_upload",
+    "pbf_upload_device", "pbf_set_colliders", "pbf_set_solver_iterations", "pbf_set_gravity",
+    "pbf_predict", "pbf_build_grid", "pbf_compute_rest_density", "pbf_solve", "pbf_finalize",
+    "pbf_step", "pbf_sync", "pbf_download", "pbf_get_scalars", "pbf_get_cells",
+    "pbf_get_neighbors", "pbf_get_stats", "pbf_get_rest_density", "pbf_num_particles",
+    "pbf_profile_enable", "pbf_profile_reset", "pbf_profile_read", "pbf_num_phases",
+    "pbf_phase_name",
+]
+
+_lib = None
+
+
+def _fp(dtype):
+    return np.ctypeslib.ndpointer(dtype=dtype, flags="C_CONTIGUOUS")
+
+
+def load_library(path: os.PathLike | None = None):
+    """dlopen libpbf_hip.so and declare prototypes.  Raises if the extension is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise PbfError(PBF_ERR_NO_DEVICE,
+                       f"HIP extension not built: {p} (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    lib = C.CDLL(str(p))
+    vp = C.c_void_p
+    lib.pbf_default_params.argtypes = [C.POINTER(PbfParams)]
+    lib.pbf_create.argtypes = [C.POINTER(PbfParams), C.c_int, C.POINTER(vp)]
+    lib.pbf_destroy.argtypes = [vp]
+    lib.pbf_last_error.argtypes = [vp]
+    lib.pbf_last_error.restype = C.c_char_p
+    lib.pbf_upload.argtypes = [vp, vp, vp, vp, C.c_float, C.c_uint32]
+    lib.pbf_upload_device.argtypes = [vp, vp, vp, vp, C.c_float, C.c_uint32]
+    lib.pbf_set_colliders.argtypes = [vp, C.POINTER(PbfCollider), C.c_uint32]
+    lib.pbf_set_solver_iterations.argtypes = [vp, C.c_int32]
+    lib.pbf_set_gravity.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+    lib.pbf_predict.argtypes = [vp, C.c_float]
+    lib.pbf_build_grid.argtypes = [vp]
+    lib.pbf_compute_rest_density.argtypes = [vp]
+    lib.pbf_solve.argtypes = [vp, C.c_int32, C.c_float]
+    lib.pbf_finalize.argtypes = [vp, C.c_float]
+    lib.pbf_step.argtypes = [vp, C.c_float]
+    lib.pbf_sync.argtypes = [vp]
+    lib.pbf_download.argtypes = [vp, vp, vp, vp]
+    lib.pbf_get_scalars.argtypes = [vp, vp, vp, vp]
+    lib.pbf_get_cells.argtypes = [vp, vp, vp, vp, vp]
+    lib.pbf_get_neighbors.argtypes = [vp, vp, vp, C.c_uint32]
+    lib.pbf_get_stats.argtypes = [vp, C.POINTER(PbfStats)]
+    lib.pbf_get_rest_density.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pbf_num_particles.argtypes = [vp]
+    lib.pbf_num_particles.restype = C.c_uint32
+    lib.pbf_profile_enable.argtypes = [vp, C.c_int]
+    lib.pbf_profile_reset.argtypes = [vp]
+    lib.pbf_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_uint32]
+    lib.pbf_num_phases.restype = C.c_uint32
+    lib.pbf_phase_name.argtypes = [C.c_uint32]
+    lib.pbf_phase_name.restype = C.c_char_p
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class PbfContext:
+    """Thin owner of one pbf_ctx.  Mirrors the C ABI one to one; raises PbfError on failure."""
+
+    def __init__(self, params: PbfParams, device: int = -1):
+        self.lib = load_library()
+        self.params = params.copy()
+        self._h = C.c_void_p()
+        rc = self.lib.pbf_create(C.byref(self.params), int(device), C.byref(self._h))
+        if rc != PBF_OK:
+            msg = self.lib.pbf_last_error(self._h if self._h else None)
+            raise PbfError(rc, (msg or b"pbf_create failed").decode())
+        self.n = 0
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None) and self._h:
+            self.lib.pbf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != PBF_OK:
+            raise PbfError(rc, self.lib.pbf_last_error(self._h).decode())
+
+    # -- setup
+    def upload(self, pos, vel=None, mass=None, uniform_mass: float = 1.0):
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+        n = pos.shape[0]
+        vel = None if vel is None else np.ascontiguousarray(vel, dtype=np.float32).reshape(n, 3)
+        mass = None if mass is None else np.ascontiguousarray(mass, dtype=np.float32).reshape(n)
+        self._ck(self.lib.pbf_upload(self._h, _ptr(pos), _ptr(vel), _ptr(mass),
+                                     C.c_float(uniform_mass), n))
+        self.n = n
+
+    def upload_device(self, d_pos: int, d_vel: int, d_mass: int, uniform_mass: float, n: int):
+        self._ck(self.lib.pbf_upload_device(self._h, C.c_void_p(d_pos), C.c_void_p(d_vel or None),
+                                            C.c_void_p(d_mass or None), C.c_float(uniform_mass), n))
+        self.n = n
+
+    def set_colliders(self, cols):
+        self._ck(self.lib.pbf_set_colliders(self._h, collider_array(cols), len(cols)))
+
+    def set_solver_iterations(self, it: int):
+        self._ck(self.lib.pbf_set_solver_iterations(self._h, it))
+
+    def set_gravity(self, gx, gy, gz):
+        self._ck(self.lib.pbf_set_gravity(self._h, gx, gy, gz))
+
+    # -- the sub-steps
+    def predict(self, dt):
+        self._ck(self.lib.pbf_predict(self._h, C.c_float(dt)))
+
+    def build_grid(self):
+        self._ck(self.lib.pbf_build_grid(self._h))
+
+    def compute_rest_density(self):
+        self._ck(self.lib.pbf_compute_rest_density(self._h))
+
+    def solve(self, dt, iterations: int = 0):
+        self._ck(self.lib.pbf_solve(self._h, iterations, C.c_float(dt)))
+
+    def finalize(self, dt):
+        self._ck(self.lib.pbf_finalize(self._h, C.c_float(dt)))
+
+    def step(self, dt):
+        self._ck(self.lib.pbf_step(self._h, C.c_float(dt)))
+
+    def sync(self):
+        self._ck(self.lib.pbf_sync(self._h))
+
+    # -- read-back
+    def download(self):
+        n = self.n
+        pos = np.empty((n, 3), np.float32)
+        vel = np.empty((n, 3), np.float32)
+        pred = np.empty((n, 3), np.float32)
+        self._ck(self.lib.pbf_download(self._h, _ptr(pos), _ptr(vel), _ptr(pred)))
+        return pos, vel, pred
+
+    def scalars(self):
+        n = self.n
+        d = np.empty(n, np.float32)
+        c = np.empty(n, np.float32)
+        lam = np.empty(n, np.float32)
+        self._ck(self.lib.pbf_get_scalars(self._h, _ptr(d), _ptr(c), _ptr(lam)))
+        return d, c, lam
+
+    def cells(self):
+        n = self.n
+        g = self.params.grid_dim
+        ncell = int(g[0]) * int(g[1]) * int(g[2])
+        xyz = np.empty((n, 3), np.int32)
+        key = np.empty(n, np.uint32)
+        sid = np.empty(n, np.uint32)
+        start = np.empty(ncell + 1, np.uint32)
+        self._ck(self.lib.pbf_get_cells(self._h, _ptr(xyz), _ptr(key), _ptr(sid), _ptr(start)))
+        return xyz, key, sid, start
+
+    def neighbors(self):
+        n = self.n
+        stride = int(self.params.max_neighbors)
+        counts = np.empty(n, np.uint32)
+        nb = np.zeros((n, stride), np.uint32)
+        self._ck(self.lib.pbf_get_neighbors(self._h, _ptr(counts), _ptr(nb), stride))
+        return counts, nb
+
+    def stats(self) -> PbfStats:
+        s = PbfStats()
+        self._ck(self.lib.pbf_get_stats(self._h, C.byref(s)))
+        return s
+
+    def rest_density(self) -> float:
+        v = C.c_float()
+        self._ck(self.lib.pbf_get_rest_density(self._h, C.byref(v)))
+        return float(v.value)
+
+    # -- device-time profile
+    def profile_enable(self, on=True):
+        self._ck(self.lib.pbf_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._ck(self.lib.pbf_profile_reset(self._h))
+
+    def profile_read(self) -> dict:
+        k = int(self.lib.pbf_num_phases())
+        ms = (C.c_double * k)()
+        calls = (C.c_uint64 * k)()
+        self._ck(self.lib.pbf_profile_read(self._h, ms, calls, k))
+        return {self.lib.pbf_phase_name(i).decode(): (float(ms[i]), int(calls[i])) for i in range(k)}

@@ -1,0 +1,1520 @@
+// pbf_hip.hip -- MI355X (gfx950) Position-Based-Fluids sub-step behind include/pbf.h.
+//
+// Data layout in HBM (all arrays live in SORTED order: cell-major, original id inside a
+// cell -- the order of the reference's hash buckets, NeighborSearch.cpp:154-185):
+//   pos [cap] float4  (x, y, z, mass)         m_positions + m_mass
+//   vel [cap] float4  (vx, vy, vz, 0)          m_velocity
+//   prd [cap] float4  (x*, y*, z*, lambda)     m_predict_positions == m_new_positions, m_lambda
+//   id  [cap] u32     original particle id
+//   nbr [K][cap] u32  neighbour table, row k = k-th neighbour of every particle
+//                      (m_search_cache transposed so a wave reads one row coalesced)
+// pos/vel/prd/id are double-buffered: the counting sort gathers them into the other copy.
+// prd has a third copy for the Jacobi hand-over (UpdatePredictPosition).
+//
+// Kernels are one thread per particle, 256-thread workgroups (4 wave64), no MFMA: every
+// phase is HBM/L2-bandwidth or latency bound.  Compiled with -ffp-contract=off.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pbf.h"
+#include "pbf_device.h"
+
+using namespace pbf;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;                     // items per thread in the scan tiles
+constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;     // 2048 cells per workgroup
+constexpr uint32_t MAX_SCAN_BLOCKS = 8192;        // second level handled by one workgroup
+constexpr float REF_PI = 3.1415926f;              // reference common.h:8
+
+enum Phase {
+    PH_PREDICT = 0,
+    PH_SORT,
+    PH_NEIGHBORS,
+    PH_REST_DENSITY,
+    PH_LAMBDA,
+    PH_DELTA,
+    PH_FINALIZE,
+    PH_VISCOSITY,
+    PH_COUNT
+};
+const char* kPhaseNames[PH_COUNT] = {"predict", "sort",     "neighbors", "rest_density",
+                                     "lambda",  "delta",    "finalize",  "viscosity"};
+
+// ------------------------------------------------------------------------------------
+// device flags written by kernels, read at sync
+struct DevFlags {
+    uint32_t neighbor_overflow;  // particles whose neighbour count exceeded K
+    uint32_t max_count;
+};
+
+// ------------------------------------------------------------------------------------
+// upload / download helpers
+
+__global__ void k_pack(const float* __restrict__ pos3, const float* __restrict__ vel3,
+                       const float* __restrict__ mass, float uniform_mass, uint32_t n,
+                       float4* __restrict__ pos, float4* __restrict__ vel, float4* __restrict__ prd,
+                       uint32_t* __restrict__ id) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float x = pos3[3 * (size_t)i], y = pos3[3 * (size_t)i + 1], z = pos3[3 * (size_t)i + 2];
+    float m = mass ? mass[i] : uniform_mass;
+    pos[i] = make_float4(x, y, z, m);
+    prd[i] = make_float4(x, y, z, 0.f);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vel3) {
+        v.x = vel3[3 * (size_t)i];
+        v.y = vel3[3 * (size_t)i + 1];
+        v.z = vel3[3 * (size_t)i + 2];
+    }
+    vel[i] = v;
+    id[i] = i;
+}
+
+// scatter a float4 array's xyz back to original-id order as float triples
+__global__ void k_unpack3(const float4* __restrict__ a, const uint32_t* __restrict__ id, uint32_t n,
+                          float* __restrict__ out3) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 v = a[i];
+    size_t o = 3 * (size_t)id[i];
+    out3[o] = v.x;
+    out3[o + 1] = v.y;
+    out3[o + 2] = v.z;
+}
+
+__global__ void k_unpack_scalars(const float* __restrict__ dens, const float* __restrict__ C,
+                                 const float4* __restrict__ prd, const uint32_t* __restrict__ id,
+                                 uint32_t n, float* __restrict__ o_dens, float* __restrict__ o_C,
+                                 float* __restrict__ o_lam) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t o = id[i];
+    o_dens[o] = dens[i];
+    o_C[o] = C[i];
+    o_lam[o] = prd[i].w;
+}
+
+// ------------------------------------------------------------------------------------
+// a6 + a7: Simulation::PredictPositions (Simulation.cpp:578-599) fused with
+// Simulation::CollisionDetection / ParticleSet::OnCollision (Simulation.cpp:723-751,
+// Particle.cpp:217-338), then NeighborSearch::Flooring + cell histogram (a8, first third).
+
+__device__ __forceinline__ void collide(const ColliderSet& cs, float px, float py, float pz,
+                                        float dt, float& vx, float& vy, float& vz, float& qx,
+                                        float& qy, float& qz) {
+    for (uint32_t c = 0; c < cs.count; ++c) {
+        const pbf_collider& col = cs.c[c];
+        float nx, ny, nz;
+        if (col.type == PBF_COLLIDER_PLANE) {
+            // CollisionDetection::PointPlaneIntersection, CollisionDetection.cpp:62-67
+            float dot_val = dot3(col.a[0], col.a[1], col.a[2], qx, qy, qz);
+            if (!(dot_val <= col.d)) continue;
+            nx = col.a[0];
+            ny = col.a[1];
+            nz = col.a[2];
+        } else {
+            // CollisionDetection::PointAABBIntersection, CollisionDetection.cpp:29-34
+            bool inside = qx < col.b[0] && qx > col.a[0] && qy < col.b[1] && qy > col.a[1] &&
+                          qz < col.b[2] && qz > col.a[2];
+            if (!inside) continue;
+            // Particle.cpp:272-303: face with the LARGEST distance (sic)
+            float dmax[3] = {col.b[0] - qx, col.b[1] - qy, col.b[2] - qz};
+            float dmin[3] = {qx - col.a[0], qy - col.a[1], qz - col.a[2]};
+            float min_dist = dmax[0];
+            int pick = 0;
+            if (min_dist < dmax[1]) min_dist = dmax[1], pick = 1;
+            if (min_dist < dmax[2]) min_dist = dmax[2], pick = 2;
+            if (min_dist < dmin[0]) min_dist = dmin[0], pick = 3;
+            if (min_dist < dmin[1]) min_dist = dmin[1], pick = 4;
+            if (min_dist < dmin[2]) min_dist = dmin[2], pick = 5;
+            float sgn = pick < 3 ? 1.f : -1.f;
+            int ax = pick % 3;
+            nx = ax == 0 ? sgn : 0.f;
+            ny = ax == 1 ? sgn : 0.f;
+            nz = ax == 2 ? sgn : 0.f;
+        }
+        // v_r = v - 2.f * dot(v, n) * n  (Particle.cpp:306,325)
+        float s = 2.f * dot3(vx, vy, vz, nx, ny, nz);
+        vx = vx - s * nx;
+        vy = vy - s * ny;
+        vz = vz - s * nz;
+        // restitution (Particle.cpp:333)
+        vx = cs.restitution * vx;
+        vy = cs.restitution * vy;
+        vz = cs.restitution * vz;
+        // re-prediction from the old position (Particle.cpp:336)
+        qx = px + dt * vx;
+        qy = py + dt * vy;
+        qz = pz + dt * vz;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_predict(const float4* __restrict__ pos,
+                                                   float4* __restrict__ vel,
+                                                   float4* __restrict__ prd,
+                                                   uint32_t* __restrict__ key,
+                                                   uint32_t* __restrict__ cell_count, uint32_t n,
+                                                   float dt, float gx, float gy, float gz,
+                                                   ColliderSet cs, GridConsts G) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pos[i];
+    float4 v = vel[i];
+    float m = p.w;
+    float minv = 1.f / m;  // m_massInv, Particle.cpp:184
+    // m_force = m_mass * vec3(0, g, 0); v = v + dt * massInv * force
+    float fx = m * gx, fy = m * gy, fz = m * gz;
+    float s = dt * minv;
+    float vx = v.x + s * fx, vy = v.y + s * fy, vz = v.z + s * fz;
+    float qx = p.x + dt * vx, qy = p.y + dt * vy, qz = p.z + dt * vz;
+    collide(cs, p.x, p.y, p.z, dt, vx, vy, vz, qx, qy, qz);
+    vel[i] = make_float4(vx, vy, vz, 0.f);
+    prd[i] = make_float4(qx, qy, qz, 0.f);
+    uint32_t k = cell_key(G, floor_cell(qx, G.spacing), floor_cell(qy, G.spacing),
+                          floor_cell(qz, G.spacing));
+    key[i] = k;
+    atomicAdd(&cell_count[k], 1u);
+}
+
+// re-key without predicting (pbf_build_grid called on its own)
+__global__ __launch_bounds__(BLOCK) void k_rekey(const float4* __restrict__ prd,
+                                                 uint32_t* __restrict__ key,
+                                                 uint32_t* __restrict__ cell_count, uint32_t n,
+                                                 GridConsts G) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 q = prd[i];
+    uint32_t k = cell_key(G, floor_cell(q.x, G.spacing), floor_cell(q.y, G.spacing),
+                          floor_cell(q.z, G.spacing));
+    key[i] = k;
+    atomicAdd(&cell_count[k], 1u);
+}
+
+// ------------------------------------------------------------------------------------
+// a8, second third: exclusive prefix scan of the cell histogram.
+// wave64 inclusive scan with DPP-backed shuffles, LDS across the 4 waves of a workgroup.
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over the workgroup; returns the exclusive prefix
+// and the workgroup total in `total`
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds_waves,
+                                                    uint32_t& total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) lds_waves[wid] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        uint32_t s = lds_waves[w];
+        if (w < wid) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scan_tile_sums(const uint32_t* __restrict__ count,
+                                                          uint32_t ncell,
+                                                          uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t lds_waves[BLOCK / 64];
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint32_t c = base + k;
+        s += (c < ncell) ? count[c] : 0u;
+    }
+    uint32_t total;
+    block_excl_scan(s, lds_waves, total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// one workgroup scans up to MAX_SCAN_BLOCKS tile sums in place (exclusive)
+__global__ __launch_bounds__(BLOCK) void k_scan_sums(uint32_t* __restrict__ tile_sums,
+                                                     uint32_t ntiles) {
+    __shared__ uint32_t lds_waves[BLOCK / 64];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < ntiles; base += BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < ntiles ? tile_sums[i] : 0u;
+        uint32_t total;
+        uint32_t ex = block_excl_scan(v, lds_waves, total);
+        if (i < ntiles) tile_sums[i] = carry + ex;
+        carry += total;
+    }
+}
+
+// writes cell_start (exclusive prefix), a cursor copy for the scatter, and clears the
+// histogram for the next sub-step (so no per-step memset is needed)
+__global__ __launch_bounds__(BLOCK) void k_scan_apply(uint32_t* __restrict__ count, uint32_t ncell,
+                                                      const uint32_t* __restrict__ tile_sums,
+                                                      uint32_t* __restrict__ cell_start,
+                                                      uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t lds_waves[BLOCK / 64];
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t c[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint32_t idx = base + k;
+        c[k] = (idx < ncell) ? count[idx] : 0u;
+        s += c[k];
+    }
+    uint32_t total;
+    uint32_t ex = block_excl_scan(s, lds_waves, total) + tile_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint32_t idx = base + k;
+        if (idx < ncell) {
+            cell_start[idx] = ex;
+            cursor[idx] = ex;
+            count[idx] = 0u;
+        }
+        ex += c[k];
+    }
+    // sentinel: cell_start[ncell] = n
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == BLOCK - 1) cell_start[ncell] = ex;
+}
+
+// ------------------------------------------------------------------------------------
+// a8, last third: counting-sort scatter (arbitrary order inside a cell), then a rank-by-id
+// pass inside each cell that makes the order deterministic and equal to a stable sort of
+// the original indices -- the reference's bucket order -- fused with the reorder gather.
+
+__global__ __launch_bounds__(BLOCK) void k_scatter(const uint32_t* __restrict__ key,
+                                                   const uint32_t* __restrict__ id,
+                                                   uint32_t* __restrict__ cursor, uint32_t n,
+                                                   uint32_t* __restrict__ tmp_src,
+                                                   uint32_t* __restrict__ tmp_id) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t slot = atomicAdd(&cursor[key[i]], 1u);
+    tmp_src[slot] = i;
+    tmp_id[slot] = id[i];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_reorder(
+    const uint32_t* __restrict__ key, const uint32_t* __restrict__ cell_start,
+    const uint32_t* __restrict__ tmp_src, const uint32_t* __restrict__ tmp_id, uint32_t n,
+    const float4* __restrict__ pos_in, const float4* __restrict__ vel_in,
+    const float4* __restrict__ prd_in, float4* __restrict__ pos_out, float4* __restrict__ vel_out,
+    float4* __restrict__ prd_out, uint32_t* __restrict__ id_out) {
+    uint32_t s = blockIdx.x * BLOCK + threadIdx.x;
+    if (s >= n) return;
+    uint32_t src = tmp_src[s];
+    uint32_t my = tmp_id[s];
+    uint32_t k = key[src];
+    uint32_t a = cell_start[k], b = cell_start[k + 1];
+    uint32_t rank = 0;
+    for (uint32_t t = a; t < b; ++t) rank += (tmp_id[t] < my) ? 1u : 0u;
+    uint32_t dst = a + rank;
+    pos_out[dst] = pos_in[src];
+    vel_out[dst] = vel_in[src];
+    prd_out[dst] = prd_in[src];
+    id_out[dst] = my;
+}
+
+// ------------------------------------------------------------------------------------
+// a8: the 27-cell sweep of NeighborSearch::SpatialSearch (NeighborSearch.cpp:187-234):
+// x outermost, z innermost, bucket order inside a cell, j != i, dist2 <= h*h (inclusive).
+// Cells are z-fastest in the key, so the visiting order equals the reference's.
+
+__global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ prd,
+                                                     const uint32_t* __restrict__ cell_start,
+                                                     uint32_t n, uint32_t cap, uint32_t K,
+                                                     GridConsts G, float square_h,
+                                                     uint32_t* __restrict__ nbr,
+                                                     uint32_t* __restrict__ nbr_count,
+                                                     DevFlags* __restrict__ flags) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 xi = prd[i];
+    int32_t cx = floor_cell(xi.x, G.spacing), cy = floor_cell(xi.y, G.spacing),
+            cz = floor_cell(xi.z, G.spacing);
+    uint32_t cnt = 0;
+    for (int dx = -1; dx <= 1; ++dx) {
+        uint32_t wx = (uint32_t)wrap(cx + dx, G.gx);
+        for (int dy = -1; dy <= 1; ++dy) {
+            uint32_t wy = (uint32_t)wrap(cy + dy, G.gy);
+            uint32_t row = (wx * (uint32_t)G.gy + wy) * (uint32_t)G.gz;
+            for (int dz = -1; dz <= 1; ++dz) {
+                uint32_t k = row + (uint32_t)wrap(cz + dz, G.gz);
+                uint32_t a = cell_start[k], b = cell_start[k + 1];
+                for (uint32_t j = a; j < b; ++j) {
+                    if (j == i) continue;
+                    float4 xj = prd[j];
+                    // glm::distance2(pi, pj) = dot(pj - pi, pj - pi)
+                    float ex = xj.x - xi.x, ey = xj.y - xi.y, ez = xj.z - xi.z;
+                    float d2 = dot3(ex, ey, ez, ex, ey, ez);
+                    if (d2 <= square_h) {
+                        if (cnt < K) nbr[(size_t)cnt * cap + i] = j;
+                        ++cnt;
+                    }
+                }
+            }
+        }
+    }
+    nbr_count[i] = cnt < K ? cnt : K;
+    if (cnt > K) atomicAdd(&flags->neighbor_overflow, 1u);
+    atomicMax(&flags->max_count, cnt);
+}
+
+// ------------------------------------------------------------------------------------
+// a9: Simulation::ComputeRestDensity (Simulation.cpp:273-300): CURRENT positions with the
+// neighbour lists of the predicted ones; mean taken serially in original-id order in fp32.
+
+__global__ __launch_bounds__(BLOCK) void k_rest_density_terms(
+    const float4* __restrict__ pos, const uint32_t* __restrict__ id,
+    const uint32_t* __restrict__ nbr, const uint32_t* __restrict__ nbr_count, uint32_t n,
+    uint32_t cap, KernConsts kc, float* __restrict__ dens_by_id) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 pi = pos[i];
+    float dens = pi.w * kc.w_zero;
+    uint32_t cnt = nbr_count[i];
+    for (uint32_t k = 0; k < cnt; ++k) {
+        uint32_t j = nbr[(size_t)k * cap + i];
+        float4 pj = pos[j];
+        float ex = pj.x - pi.x, ey = pj.y - pi.y, ez = pj.z - pi.z;
+        float distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+        dens += pj.w * poly6_strict(kc, distance);
+    }
+    dens_by_id[id[i]] = dens;
+}
+
+__global__ void k_rest_density_mean(const float* __restrict__ dens_by_id, uint32_t n,
+                                    float* __restrict__ rho0) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float acc = 0.f;
+    for (uint32_t i = 0; i < n; ++i) acc += dens_by_id[i];
+    acc /= (float)n;
+    *rho0 = acc;
+}
+
+// ------------------------------------------------------------------------------------
+// a13 + a14 fused: Simulation::ComputeDensity and ComputeLambdas (Simulation.cpp:607-679)
+// share one pass over the neighbour row: rho_i and sum_j |gradW/rho0|^2 are independent.
+// lambda is written into prd[i].w (no reader uses .w during this kernel).
+
+template <bool STRICT>
+__global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __restrict__ pos,
+                                                  const uint32_t* __restrict__ nbr,
+                                                  const uint32_t* __restrict__ nbr_count,
+                                                  uint32_t n, uint32_t cap, KernConsts kc,
+                                                  const float* __restrict__ rho0_ptr,
+                                                  float* __restrict__ dens_out,
+                                                  float* __restrict__ C_out) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float rho0 = *rho0_ptr;
+    const float inv_rho0 = 1.f / rho0;
+    const float4 xi = prd[i];
+    float dens = pos[i].w * kc.w_zero;
+    float grad_sum = 0.f;  // self term: |(1/rho0) gradW(0)|^2 == 0 (Simulation.cpp:657-658)
+    const uint32_t cnt = nbr_count[i];
+    for (uint32_t k = 0; k < cnt; ++k) {
+        uint32_t j = nbr[(size_t)k * cap + i];
+        float4 xj = prd[j];
+        float mj = pos[j].w;
+        float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+        float d2 = dot3(dx, dy, dz, dx, dy, dz);
+        float w, gs;
+        if (STRICT) {
+            float distance = sqrtf(d2);
+            w = poly6_strict(kc, distance);
+            gs = grad_scalar_strict(kc, distance);
+        } else {
+            w = poly6_fast(kc, d2);
+            gs = grad_scalar_fast(kc, d2);
+        }
+        dens += mj * w;
+        // gradientC_j = (1/rho0) * (gs * diff); sum += dot(gC, gC)
+        float gx = inv_rho0 * (gs * dx), gy = inv_rho0 * (gs * dy), gz = inv_rho0 * (gs * dz);
+        grad_sum += dot3(gx, gy, gz, gx, gy, gz);
+    }
+    float C = dens / rho0 - 1.f;
+    float lam = -C;
+    lam /= grad_sum + kc.epsilon;
+    dens_out[i] = dens;
+    C_out[i] = C;
+    reinterpret_cast<float*>(prd)[4 * (size_t)i + 3] = lam;
+}
+
+// a15 + a16: Simulation::ComputeSPHParticlesCorrection (Simulation.cpp:681-712) writing the
+// Jacobi hand-over copy directly (UpdatePredictPosition, :714-721), plus the build-side
+// container clamp.  Accumulates onto new_i in neighbour-row order like the reference.
+
+template <bool STRICT>
+__global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
+                                                 float4* __restrict__ prd_out,
+                                                 const uint32_t* __restrict__ nbr,
+                                                 const uint32_t* __restrict__ nbr_count,
+                                                 uint32_t n, uint32_t cap, KernConsts kc,
+                                                 const float* __restrict__ rho0_ptr,
+                                                 int container, float3_ cmin, float3_ cmax) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float inv_rho0 = 1.f / *rho0_ptr;
+    const float4 xi = prd[i];
+    float nx = xi.x, ny = xi.y, nz = xi.z;
+    const uint32_t cnt = nbr_count[i];
+    for (uint32_t k = 0; k < cnt; ++k) {
+        uint32_t j = nbr[(size_t)k * cap + i];
+        float4 xj = prd[j];
+        float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+        float d2 = dot3(dx, dy, dz, dx, dy, dz);
+        float sc, gs;
+        if (STRICT) {
+            float distance = sqrtf(d2);
+            sc = scorr_strict(kc, poly6_strict(kc, distance));
+            gs = grad_scalar_strict(kc, distance);
+        } else {
+            sc = scorr_fast(kc, poly6_fast(kc, d2));
+            gs = grad_scalar_fast(kc, d2);
+        }
+        // result = (1/rho0) * (lambda_i + lambda_j + (float)scorr) * gradW
+        float s = inv_rho0 * (xi.w + xj.w + sc);
+        nx += s * (gs * dx);
+        ny += s * (gs * dy);
+        nz += s * (gs * dz);
+    }
+    if (container) {
+        nx = nx < cmin.x ? cmin.x : nx;
+        nx = nx > cmax.x ? cmax.x : nx;
+        ny = ny < cmin.y ? cmin.y : ny;
+        ny = ny > cmax.y ? cmax.y : ny;
+        nz = nz < cmin.z ? cmin.z : nz;
+        nz = nz > cmax.z ? cmax.z : nz;
+    }
+    prd_out[i] = make_float4(nx, ny, nz, xi.w);
+}
+
+// a18: ParticleSet::Update (Particle.cpp:207-215): v = (new - p) / dt; p = new
+__global__ __launch_bounds__(BLOCK) void k_finalize(float4* __restrict__ pos,
+                                                    float4* __restrict__ vel,
+                                                    const float4* __restrict__ prd, uint32_t n,
+                                                    float dt) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pos[i];
+    float4 q = prd[i];
+    vel[i] = make_float4((q.x - p.x) / dt, (q.y - p.y) / dt, (q.z - p.z) / dt, 0.f);
+    pos[i] = make_float4(q.x, q.y, q.z, p.w);
+}
+
+// ------------------------------------------------------------------------------------
+// a20 (no reference counterpart): vorticity confinement + XSPH viscosity after Macklin &
+// Mueller 2013 eqs. 15-17 on the frozen neighbour rows and the updated positions.
+
+__global__ __launch_bounds__(BLOCK) void k_vorticity(const float4* __restrict__ pos,
+                                                     const float4* __restrict__ vel,
+                                                     const uint32_t* __restrict__ nbr,
+                                                     const uint32_t* __restrict__ nbr_count,
+                                                     uint32_t n, uint32_t cap, KernConsts kc,
+                                                     float4* __restrict__ omega) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 pi = pos[i];
+    const float4 vi = vel[i];
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    const uint32_t cnt = nbr_count[i];
+    for (uint32_t k = 0; k < cnt; ++k) {
+        uint32_t j = nbr[(size_t)k * cap + i];
+        float4 pj = pos[j];
+        float4 vj = vel[j];
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        float gs = grad_scalar_strict(kc, distance);
+        float gx = gs * dx, gy = gs * dy, gz = gs * dz;
+        float ux = vj.x - vi.x, uy = vj.y - vi.y, uz = vj.z - vi.z;
+        wx += uy * gz - gy * uz;
+        wy += uz * gx - gz * ux;
+        wz += ux * gy - gx * uy;
+    }
+    omega[i] = make_float4(wx, wy, wz, sqrtf(dot3(wx, wy, wz, wx, wy, wz)));
+}
+
+__global__ __launch_bounds__(BLOCK) void k_vorticity_apply(
+    const float4* __restrict__ pos, const float4* __restrict__ vel,
+    const float4* __restrict__ omega, const uint32_t* __restrict__ nbr,
+    const uint32_t* __restrict__ nbr_count, uint32_t n, uint32_t cap, KernConsts kc,
+    const float* __restrict__ rho0_ptr, float dt, float eps_v, float4* __restrict__ vel_out) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float inv_rho0 = 1.f / *rho0_ptr;
+    const float4 pi = pos[i];
+    float ex = 0.f, ey = 0.f, ez = 0.f;
+    const uint32_t cnt = nbr_count[i];
+    for (uint32_t k = 0; k < cnt; ++k) {
+        uint32_t j = nbr[(size_t)k * cap + i];
+        float4 pj = pos[j];
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        float gs = grad_scalar_strict(kc, distance);
+        float s = (pj.w * inv_rho0) * omega[j].w;
+        ex += s * (gs * dx);
+        ey += s * (gs * dy);
+        ez += s * (gs * dz);
+    }
+    float len = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+    float4 v = vel[i];
+    if (len > 0.f) {
+        float Nx = ex / len, Ny = ey / len, Nz = ez / len;
+        float4 w = omega[i];
+        float fx = Ny * w.z - w.y * Nz;
+        float fy = Nz * w.x - w.z * Nx;
+        float fz = Nx * w.y - w.x * Ny;
+        float s = dt * eps_v;
+        v.x = v.x + s * fx;
+        v.y = v.y + s * fy;
+        v.z = v.z + s * fz;
+    }
+    vel_out[i] = v;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_xsph(const float4* __restrict__ pos,
+                                                const float4* __restrict__ vel,
+                                                const uint32_t* __restrict__ nbr,
+                                                const uint32_t* __restrict__ nbr_count,
+                                                uint32_t n, uint32_t cap, KernConsts kc,
+                                                const float* __restrict__ rho0_ptr, float c,
+                                                float4* __restrict__ vel_out) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float inv_rho0 = 1.f / *rho0_ptr;
+    const float4 pi = pos[i];
+    const float4 vi = vel[i];
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    const uint32_t cnt = nbr_count[i];
+    for (uint32_t k = 0; k < cnt; ++k) {
+        uint32_t j = nbr[(size_t)k * cap + i];
+        float4 pj = pos[j];
+        float4 vj = vel[j];
+        float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+        float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        float s = (pj.w * inv_rho0) * poly6_strict(kc, distance);
+        ax += s * (vj.x - vi.x);
+        ay += s * (vj.y - vi.y);
+        az += s * (vj.z - vi.z);
+    }
+    vel_out[i] = make_float4(vi.x + c * ax, vi.y + c * ay, vi.z + c * az, 0.f);
+}
+
+// ------------------------------------------------------------------------------------
+// diagnostics
+
+__global__ __launch_bounds__(BLOCK) void k_cells_by_id(const float4* __restrict__ prd,
+                                                       const uint32_t* __restrict__ id, uint32_t n,
+                                                       GridConsts G, int32_t* __restrict__ xyz,
+                                                       uint32_t* __restrict__ key) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 q = prd[i];
+    int32_t cx = floor_cell(q.x, G.spacing), cy = floor_cell(q.y, G.spacing),
+            cz = floor_cell(q.z, G.spacing);
+    uint32_t o = id[i];
+    xyz[3 * (size_t)o] = cx;
+    xyz[3 * (size_t)o + 1] = cy;
+    xyz[3 * (size_t)o + 2] = cz;
+    key[o] = cell_key(G, cx, cy, cz);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_neighbors_by_id(const uint32_t* __restrict__ nbr,
+                                                           const uint32_t* __restrict__ nbr_count,
+                                                           const uint32_t* __restrict__ id,
+                                                           uint32_t n, uint32_t cap, uint32_t stride,
+                                                           uint32_t* __restrict__ counts,
+                                                           uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t o = id[i];
+    uint32_t cnt = nbr_count[i];
+    counts[o] = cnt;
+    for (uint32_t k = 0; k < cnt && k < stride; ++k)
+        out[(size_t)o * stride + k] = id[nbr[(size_t)k * cap + i]];
+}
+
+struct StatPartial {
+    double sum_abs_C, sum_C, max_abs_C, msum, mx, my, mz, max_speed2;
+    unsigned long long nbr_total;
+    uint32_t nonfinite, max_nbr;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_stats(const float4* __restrict__ pos,
+                                                 const float4* __restrict__ vel,
+                                                 const float* __restrict__ C,
+                                                 const uint32_t* __restrict__ nbr_count, uint32_t n,
+                                                 StatPartial* __restrict__ partials) {
+    __shared__ StatPartial sh[BLOCK / 64];
+    StatPartial a;
+    memset(&a, 0, sizeof(a));
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        float4 p = pos[i];
+        if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {
+            a.nonfinite++;
+            continue;
+        }
+        double c = C[i], ac = fabs(c);
+        a.sum_abs_C += ac;
+        a.sum_C += c;
+        a.max_abs_C = ac > a.max_abs_C ? ac : a.max_abs_C;
+        double m = p.w;
+        a.msum += m;
+        a.mx += m * p.x;
+        a.my += m * p.y;
+        a.mz += m * p.z;
+        float4 v = vel[i];
+        double s2 = (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z;
+        a.max_speed2 = s2 > a.max_speed2 ? s2 : a.max_speed2;
+        uint32_t k = nbr_count[i];
+        a.nbr_total += k;
+        a.max_nbr = k > a.max_nbr ? k : a.max_nbr;
+    }
+    // wave reduction with shuffles, then LDS across waves
+    for (int off = 32; off > 0; off >>= 1) {
+        a.sum_abs_C += __shfl_down(a.sum_abs_C, off, 64);
+        a.sum_C += __shfl_down(a.sum_C, off, 64);
+        double m1 = __shfl_down(a.max_abs_C, off, 64);
+        a.max_abs_C = m1 > a.max_abs_C ? m1 : a.max_abs_C;
+        a.msum += __shfl_down(a.msum, off, 64);
+        a.mx += __shfl_down(a.mx, off, 64);
+        a.my += __shfl_down(a.my, off, 64);
+        a.mz += __shfl_down(a.mz, off, 64);
+        double s1 = __shfl_down(a.max_speed2, off, 64);
+        a.max_speed2 = s1 > a.max_speed2 ? s1 : a.max_speed2;
+        a.nbr_total += __shfl_down(a.nbr_total, off, 64);
+        a.nonfinite += __shfl_down(a.nonfinite, off, 64);
+        uint32_t k1 = __shfl_down(a.max_nbr, off, 64);
+        a.max_nbr = k1 > a.max_nbr ? k1 : a.max_nbr;
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        StatPartial t = sh[0];
+        for (int w = 1; w < BLOCK / 64; ++w) {
+            const StatPartial& b = sh[w];
+            t.sum_abs_C += b.sum_abs_C;
+            t.sum_C += b.sum_C;
+            t.max_abs_C = b.max_abs_C > t.max_abs_C ? b.max_abs_C : t.max_abs_C;
+            t.msum += b.msum;
+            t.mx += b.mx;
+            t.my += b.my;
+            t.mz += b.mz;
+            t.max_speed2 = b.max_speed2 > t.max_speed2 ? b.max_speed2 : t.max_speed2;
+            t.nbr_total += b.nbr_total;
+            t.nonfinite += b.nonfinite;
+            t.max_nbr = b.max_nbr > t.max_nbr ? b.max_nbr : t.max_nbr;
+        }
+        partials[blockIdx.x] = t;
+    }
+}
+
+}  // namespace
+
+// ======================================================================================
+// host side
+
+struct pbf_ctx {
+    pbf_params P;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t n = 0, cap = 0, K = 0, ncell = 0, ntiles = 0;
+    int cur = 0;  // which copy of pos/vel/id is live
+    float4* pos[2] = {nullptr, nullptr};
+    float4* vel[2] = {nullptr, nullptr};
+    float4* prd[3] = {nullptr, nullptr, nullptr};
+    int prd_cur = 0;  // live predicted/new positions
+    uint32_t* id[2] = {nullptr, nullptr};
+    uint32_t *key = nullptr, *tmp_src = nullptr, *tmp_id = nullptr;
+    uint32_t *cell_count = nullptr, *cell_start = nullptr, *cursor = nullptr, *tile_sums = nullptr;
+    uint32_t *nbr = nullptr, *nbr_count = nullptr;
+    float *dens = nullptr, *C = nullptr, *rho0 = nullptr;
+    float4* omega = nullptr;
+    void* staging = nullptr;  // cap * 16 B scratch for up/downloads
+    size_t staging_bytes = 0;
+    DevFlags* flags = nullptr;
+    StatPartial* stat_partials = nullptr;
+    ColliderSet colliders;
+    bool first_frame = true;
+    bool keyed = false;  // histogram of the live prd already accumulated by k_predict
+    bool grid_valid = false;
+    int32_t iterations = 1;
+    std::string err;
+    // profiling
+    bool prof = false;
+    struct Span {
+        int phase;
+        hipEvent_t a, b;
+    };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> free_events;
+    double prof_ms[PH_COUNT] = {0};
+    uint64_t prof_calls[PH_COUNT] = {0};
+};
+
+namespace {
+
+thread_local std::string g_create_err = "no error";
+
+int fail(pbf_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    else g_create_err = msg;
+    return code;
+}
+
+#define HIP_CK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), PBF_ERR_HIP,                                                   \
+                        std::string(#call) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                            ":" + std::to_string(__LINE__) + ")");                          \
+    } while (0)
+
+#define LAUNCH_CK(c) HIP_CK(c, hipGetLastError())
+
+inline uint32_t nblocks(uint32_t n) { return (n + BLOCK - 1) / BLOCK; }
+
+// SPHKernel constants: same expressions, same libm pow, as the reference evaluates per pair
+KernConsts make_kern(const pbf_params& P, float dt) {
+    KernConsts k;
+    memset(&k, 0, sizeof(k));
+    const double h = (double)P.effective_radius;
+    const double h9 = pow(h, 9);
+    const double h6 = pow(h, 6);
+    k.h = P.effective_radius;
+    k.hd = h;
+    k.h2 = h * h;
+    k.hh = P.effective_radius * P.effective_radius;
+    k.w_coef = (315.0 / (64.0 * REF_PI * h9));
+    k.g_coef = (float)(-945.0 / (32.0 * REF_PI * h9));
+    k.spiky_coef = (-45.0 / (REF_PI * h6));
+    k.scorr_k = -P.scorr_k;
+    k.w_zero = (float)(k.w_coef * (k.h2 * k.h2 * k.h2));
+    {
+        float dq = P.scorr_dq * P.effective_radius;
+        double d = (double)dq, q = k.h2 - d * d;
+        k.w_dq = (dq >= 0 && dq <= k.h) ? (float)(k.w_coef * (q * q * q)) : 0.f;
+    }
+    k.w_coef_f = (float)k.w_coef;
+    k.spiky_coef_f = (float)k.spiky_coef;
+    k.inv_w_dq = k.w_dq != 0.f ? 1.f / k.w_dq : 0.f;
+    double s = -P.scorr_k;
+    for (int t = 0; t < P.scorr_dt_power; ++t) s *= (double)dt;
+    k.scorr_scale_f = (float)s;
+    k.epsilon = P.epsilon;
+    k.dt = dt;
+    k.scorr_dt_power = P.scorr_dt_power;
+    k.grad_kernel = P.gradient_kernel;
+    return k;
+}
+
+GridConsts make_grid(const pbf_params& P) {
+    GridConsts g;
+    g.gx = P.grid_dim[0];
+    g.gy = P.grid_dim[1];
+    g.gz = P.grid_dim[2];
+    g.spacing = P.grid_spacing;
+    return g;
+}
+
+// ---- profiling spans (HIP events on the ctx stream)
+hipEvent_t get_event(pbf_ctx* c) {
+    if (!c->free_events.empty()) {
+        hipEvent_t e = c->free_events.back();
+        c->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void fold_spans(pbf_ctx* c) {
+    if (c->spans.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& s : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            c->prof_ms[s.phase] += ms;
+            c->prof_calls[s.phase] += 1;
+        }
+        c->free_events.push_back(s.a);
+        c->free_events.push_back(s.b);
+    }
+    c->spans.clear();
+}
+
+struct PhaseScope {
+    pbf_ctx* c;
+    hipEvent_t a = nullptr;
+    int phase;
+    PhaseScope(pbf_ctx* ctx, int ph) : c(ctx), phase(ph) {
+        if (c->prof) {
+            a = get_event(c);
+            if (a) (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~PhaseScope() {
+        if (a) {
+            hipEvent_t b = get_event(c);
+            if (b) {
+                (void)hipEventRecord(b, c->stream);
+                c->spans.push_back({phase, a, b});
+                if (c->spans.size() >= 8192) fold_spans(c);
+            } else {
+                c->free_events.push_back(a);
+            }
+        }
+    }
+};
+
+int validate_params(const pbf_params& P, std::string& why) {
+    if (P.abi_version != PBF_ABI_VERSION) { why = "abi_version mismatch"; return PBF_ERR_INVALID; }
+    if (P.capacity == 0) { why = "capacity must be > 0"; return PBF_ERR_INVALID; }
+    if (P.max_neighbors == 0 || P.max_neighbors > 1024) { why = "max_neighbors out of range"; return PBF_ERR_INVALID; }
+    for (int a = 0; a < 3; ++a)
+        if (P.grid_dim[a] < 3 || P.grid_dim[a] > 4096) { why = "grid_dim must be in [3, 4096]"; return PBF_ERR_INVALID; }
+    uint64_t ncell = (uint64_t)P.grid_dim[0] * P.grid_dim[1] * P.grid_dim[2];
+    if (ncell > (uint64_t)MAX_SCAN_BLOCKS * SCAN_TILE) { why = "grid has too many cells (max 16777216)"; return PBF_ERR_INVALID; }
+    if (!(P.grid_spacing > 0.f) || !(P.effective_radius > 0.f)) { why = "grid_spacing and effective_radius must be > 0"; return PBF_ERR_INVALID; }
+    if (P.effective_radius > P.grid_spacing) { why = "effective_radius must not exceed grid_spacing (27-cell sweep)"; return PBF_ERR_INVALID; }
+    if (P.solver_iterations < 0 || P.scorr_dt_power < 0 || P.scorr_dt_power > 8) { why = "bad iteration / scorr_dt_power"; return PBF_ERR_INVALID; }
+    if (P.arithmetic != PBF_ARITH_STRICT && P.arithmetic != PBF_ARITH_FAST) { why = "bad arithmetic mode"; return PBF_ERR_INVALID; }
+    if (P.gradient_kernel != PBF_GRAD_POLY6 && P.gradient_kernel != PBF_GRAD_SPIKY) { why = "bad gradient_kernel"; return PBF_ERR_INVALID; }
+    if (P.rest_density_mode != PBF_RHO0_FIRST_FRAME_MEAN && P.rest_density_mode != PBF_RHO0_FIXED) { why = "bad rest_density_mode"; return PBF_ERR_INVALID; }
+    return PBF_OK;
+}
+
+template <typename T>
+hipError_t dalloc(T** p, size_t count) {
+    return hipMalloc((void**)p, (count ? count : 1) * sizeof(T));
+}
+
+int set_device(pbf_ctx* c) {
+    HIP_CK(c, hipSetDevice(c->device));
+    return PBF_OK;
+}
+
+#define ENTER(c)                                       \
+    if (!(c)) return PBF_ERR_INVALID;                  \
+    do {                                               \
+        int rc_ = set_device(c);                       \
+        if (rc_) return rc_;                           \
+    } while (0)
+
+// sort + neighbour table of the live prd (histogram must already be in cell_count)
+int sort_and_neighbors(pbf_ctx* c) {
+    const uint32_t n = c->n;
+    GridConsts G = make_grid(c->P);
+    {
+        PhaseScope ps(c, PH_SORT);
+        k_scan_tile_sums<<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums);
+        k_scan_sums<<<1, BLOCK, 0, c->stream>>>(c->tile_sums, c->ntiles);
+        k_scan_apply<<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
+                                                         c->cell_start, c->cursor);
+        if (n) {
+            const int s = c->cur, d = 1 - c->cur;
+            const int ps_ = c->prd_cur, pd = (c->prd_cur + 1) % 3;
+            k_scatter<<<nblocks(n), BLOCK, 0, c->stream>>>(c->key, c->id[s], c->cursor, n,
+                                                           c->tmp_src, c->tmp_id);
+            k_reorder<<<nblocks(n), BLOCK, 0, c->stream>>>(
+                c->key, c->cell_start, c->tmp_src, c->tmp_id, n, c->pos[s], c->vel[s],
+                c->prd[ps_], c->pos[d], c->vel[d], c->prd[pd], c->id[d]);
+            c->cur = d;
+            c->prd_cur = pd;
+        }
+        LAUNCH_CK(c);
+    }
+    if (n) {
+        PhaseScope ps(c, PH_NEIGHBORS);
+        HIP_CK(c, hipMemsetAsync(c->flags, 0, sizeof(DevFlags), c->stream));
+        k_neighbors<<<nblocks(n), BLOCK, 0, c->stream>>>(
+            c->prd[c->prd_cur], c->cell_start, n, c->cap, c->K, G,
+            c->P.effective_radius * c->P.effective_radius, c->nbr, c->nbr_count, c->flags);
+        LAUNCH_CK(c);
+    }
+    c->keyed = false;
+    c->grid_valid = true;
+    return PBF_OK;
+}
+
+int download3(pbf_ctx* c, const float4* src, float* host) {
+    if (!host || !c->n) return PBF_OK;
+    float* st = (float*)c->staging;
+    k_unpack3<<<nblocks(c->n), BLOCK, 0, c->stream>>>(src, c->id[c->cur], c->n, st);
+    LAUNCH_CK(c);
+    HIP_CK(c, hipMemcpyAsync(host, st, (size_t)c->n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    return PBF_OK;
+}
+
+int check_flags(pbf_ctx* c) {
+    DevFlags f;
+    HIP_CK(c, hipMemcpyAsync(&f, c->flags, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    if (f.neighbor_overflow)
+        return fail(c, PBF_ERR_NEIGHBOR_OVERFLOW,
+                    std::to_string(f.neighbor_overflow) + " particles exceed max_neighbors=" +
+                        std::to_string(c->K) + " (largest count " + std::to_string(f.max_count) +
+                        "); raise pbf_params.max_neighbors");
+    return PBF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pbf_default_params(pbf_params* p) {
+    if (!p) return PBF_ERR_INVALID;
+    memset(p, 0, sizeof(*p));
+    p->abi_version = PBF_ABI_VERSION;
+    p->capacity = 0;
+    p->max_neighbors = 64;
+    p->grid_dim[0] = p->grid_dim[1] = p->grid_dim[2] = 64;  // Simulation.cpp:46
+    p->grid_spacing = 1.f;                                  // NeighborSearch.cpp:17
+    p->effective_radius = 1.f;                              // Simulation.cpp:88
+    p->gravity[0] = 0.f;
+    p->gravity[1] = -9.8f;  // Simulation.cpp:16
+    p->gravity[2] = 0.f;
+    p->epsilon = 1.0e-6f;    // Simulation.cpp:644
+    p->restitution = 0.99f;  // Particle.cpp:333
+    p->scorr_k = 0.1;        // Simulation.cpp:698
+    p->scorr_dq = 0.3f;      // Simulation.cpp:700
+    p->scorr_dt_power = 1;   // Simulation.cpp:702
+    p->rest_density_mode = PBF_RHO0_FIRST_FRAME_MEAN;
+    p->rest_density = 0.8f;    // Simulation.cpp:18
+    p->solver_iterations = 1;  // ConstraintSolver.cpp:4
+    p->arithmetic = PBF_ARITH_STRICT;
+    p->gradient_kernel = PBF_GRAD_POLY6;
+    return PBF_OK;
+}
+
+const char* pbf_last_error(const pbf_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+int pbf_create(const pbf_params* params, int device, pbf_ctx** out) {
+    if (out) *out = nullptr;
+    if (!params || !out) return fail(nullptr, PBF_ERR_INVALID, "null argument");
+    std::string why;
+    int rc = validate_params(*params, why);
+    if (rc) return fail(nullptr, rc, why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, PBF_ERR_NO_DEVICE, "no HIP device visible: the PBF path has no CPU fallback");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= ndev) return fail(nullptr, PBF_ERR_INVALID, "device index out of range");
+    pbf_ctx* c = new (std::nothrow) pbf_ctx();
+    if (!c) return fail(nullptr, PBF_ERR_INVALID, "out of host memory");
+    c->P = *params;
+    c->device = device;
+    c->cap = params->capacity;
+    c->K = params->max_neighbors;
+    c->ncell = (uint32_t)params->grid_dim[0] * params->grid_dim[1] * params->grid_dim[2];
+    c->ntiles = (c->ncell + SCAN_TILE - 1) / SCAN_TILE;
+    c->iterations = params->solver_iterations;
+    c->err = "no error";
+    memset(&c->colliders, 0, sizeof(c->colliders));
+    c->colliders.restitution = params->restitution;
+#define CREATE_CK(call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            std::string m_ = std::string(#call) + ": " + hipGetErrorString(e_);                \
+            pbf_destroy(c);                                                                    \
+            return fail(nullptr, PBF_ERR_HIP, m_);                                             \
+        }                                                                                      \
+    } while (0)
+    CREATE_CK(hipSetDevice(device));
+    CREATE_CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t cap = c->cap;
+    for (int b = 0; b < 2; ++b) {
+        CREATE_CK(dalloc(&c->pos[b], cap));
+        CREATE_CK(dalloc(&c->vel[b], cap));
+        CREATE_CK(dalloc(&c->id[b], cap));
+    }
+    for (int b = 0; b < 3; ++b) CREATE_CK(dalloc(&c->prd[b], cap));
+    CREATE_CK(dalloc(&c->key, cap));
+    CREATE_CK(dalloc(&c->tmp_src, cap));
+    CREATE_CK(dalloc(&c->tmp_id, cap));
+    CREATE_CK(dalloc(&c->cell_count, (size_t)c->ncell));
+    CREATE_CK(dalloc(&c->cell_start, (size_t)c->ncell + 1));
+    CREATE_CK(dalloc(&c->cursor, (size_t)c->ncell));
+    CREATE_CK(dalloc(&c->tile_sums, (size_t)c->ntiles));
+    CREATE_CK(dalloc(&c->nbr, cap * (size_t)c->K));
+    CREATE_CK(dalloc(&c->nbr_count, cap));
+    CREATE_CK(dalloc(&c->dens, cap));
+    CREATE_CK(dalloc(&c->C, cap));
+    CREATE_CK(dalloc(&c->rho0, 1));
+    CREATE_CK(dalloc(&c->omega, cap));
+    c->staging_bytes = cap * 16;
+    CREATE_CK(hipMalloc(&c->staging, c->staging_bytes ? c->staging_bytes : 16));
+    CREATE_CK(dalloc(&c->flags, 1));
+    CREATE_CK(dalloc(&c->stat_partials, 1024));
+    CREATE_CK(hipMemsetAsync(c->cell_count, 0, (size_t)c->ncell * 4, c->stream));
+    CREATE_CK(hipMemsetAsync(c->flags, 0, sizeof(DevFlags), c->stream));
+    CREATE_CK(hipMemsetAsync(c->nbr_count, 0, cap * 4, c->stream));
+    CREATE_CK(hipMemsetAsync(c->dens, 0, cap * 4, c->stream));
+    CREATE_CK(hipMemsetAsync(c->C, 0, cap * 4, c->stream));
+    CREATE_CK(hipMemcpyAsync(c->rho0, &c->P.rest_density, 4, hipMemcpyHostToDevice, c->stream));
+    CREATE_CK(hipStreamSynchronize(c->stream));
+#undef CREATE_CK
+    *out = c;
+    return PBF_OK;
+}
+
+int pbf_destroy(pbf_ctx* c) {
+    if (!c) return PBF_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& s : c->spans) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    for (int b = 0; b < 2; ++b) {
+        (void)hipFree(c->pos[b]);
+        (void)hipFree(c->vel[b]);
+        (void)hipFree(c->id[b]);
+    }
+    for (int b = 0; b < 3; ++b) (void)hipFree(c->prd[b]);
+    (void)hipFree(c->key);
+    (void)hipFree(c->tmp_src);
+    (void)hipFree(c->tmp_id);
+    (void)hipFree(c->cell_count);
+    (void)hipFree(c->cell_start);
+    (void)hipFree(c->cursor);
+    (void)hipFree(c->tile_sums);
+    (void)hipFree(c->nbr);
+    (void)hipFree(c->nbr_count);
+    (void)hipFree(c->dens);
+    (void)hipFree(c->C);
+    (void)hipFree(c->rho0);
+    (void)hipFree(c->omega);
+    (void)hipFree(c->staging);
+    (void)hipFree(c->flags);
+    (void)hipFree(c->stat_partials);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PBF_OK;
+}
+
+static int upload_common(pbf_ctx* c, const float* d_pos, const float* d_vel, const float* d_mass,
+                         float uniform_mass, uint32_t n) {
+    c->cur = 0;
+    c->prd_cur = 0;
+    if (n) {
+        k_pack<<<nblocks(n), BLOCK, 0, c->stream>>>(d_pos, d_vel, d_mass, uniform_mass, n, c->pos[0],
+                                                    c->vel[0], c->prd[0], c->id[0]);
+        LAUNCH_CK(c);
+    }
+    HIP_CK(c, hipMemcpyAsync(c->rho0, &c->P.rest_density, 4, hipMemcpyHostToDevice, c->stream));
+    if (c->keyed) HIP_CK(c, hipMemsetAsync(c->cell_count, 0, (size_t)c->ncell * 4, c->stream));
+    HIP_CK(c, hipMemsetAsync(c->nbr_count, 0, (size_t)c->cap * 4, c->stream));
+    HIP_CK(c, hipMemsetAsync(c->flags, 0, sizeof(DevFlags), c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    c->n = n;
+    c->first_frame = true;
+    c->keyed = false;
+    c->grid_valid = false;
+    return PBF_OK;
+}
+
+int pbf_upload(pbf_ctx* c, const float* pos, const float* vel, const float* mass,
+               float uniform_mass, uint32_t n) {
+    ENTER(c);
+    if (n > c->cap) return fail(c, PBF_ERR_CAPACITY, "n exceeds ctx capacity");
+    if (n && !pos) return fail(c, PBF_ERR_INVALID, "pos is null");
+    if (!mass && !(uniform_mass > 0.f)) return fail(c, PBF_ERR_INVALID, "uniform_mass must be > 0");
+    float *dp = nullptr, *dv = nullptr, *dm = nullptr;
+    if (n) {
+        // stage the raw triples in spare device arrays that k_pack does not write:
+        // pos -> prd[1] (16 B/particle >= 12), vel -> prd[2], mass -> staging
+        dp = (float*)c->prd[1];
+        HIP_CK(c, hipMemcpyAsync(dp, pos, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+        if (vel) {
+            dv = (float*)c->prd[2];
+            HIP_CK(c, hipMemcpyAsync(dv, vel, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+        }
+        if (mass) {
+            dm = (float*)c->staging;
+            HIP_CK(c, hipMemcpyAsync(dm, mass, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    return upload_common(c, dp, dv, dm, uniform_mass, n);
+}
+
+int pbf_upload_device(pbf_ctx* c, const void* d_pos, const void* d_vel, const void* d_mass,
+                      float uniform_mass, uint32_t n) {
+    ENTER(c);
+    if (n > c->cap) return fail(c, PBF_ERR_CAPACITY, "n exceeds ctx capacity");
+    if (n && !d_pos) return fail(c, PBF_ERR_INVALID, "d_pos is null");
+    if (!d_mass && !(uniform_mass > 0.f)) return fail(c, PBF_ERR_INVALID, "uniform_mass must be > 0");
+    return upload_common(c, (const float*)d_pos, (const float*)d_vel, (const float*)d_mass,
+                         uniform_mass, n);
+}
+
+int pbf_set_colliders(pbf_ctx* c, const pbf_collider* cols, uint32_t count) {
+    if (!c) return PBF_ERR_INVALID;
+    if (count > PBF_MAX_COLLIDERS) return fail(c, PBF_ERR_INVALID, "too many colliders");
+    if (count && !cols) return fail(c, PBF_ERR_INVALID, "colliders is null");
+    for (uint32_t i = 0; i < count; ++i)
+        if (cols[i].type != PBF_COLLIDER_PLANE && cols[i].type != PBF_COLLIDER_AABB)
+            return fail(c, PBF_ERR_INVALID,
+                        "unsupported collider type (only PLANE and AABB have a defined response "
+                        "in the reference, Particle.cpp:248-338)");
+    for (uint32_t i = 0; i < count; ++i) c->colliders.c[i] = cols[i];
+    c->colliders.count = count;
+    return PBF_OK;
+}
+
+int pbf_set_solver_iterations(pbf_ctx* c, int32_t it) {
+    if (!c) return PBF_ERR_INVALID;
+    if (it < 0) return fail(c, PBF_ERR_INVALID, "iterations must be >= 0");
+    c->iterations = it;
+    return PBF_OK;
+}
+
+int pbf_set_gravity(pbf_ctx* c, float gx, float gy, float gz) {
+    if (!c) return PBF_ERR_INVALID;
+    c->P.gravity[0] = gx;
+    c->P.gravity[1] = gy;
+    c->P.gravity[2] = gz;
+    return PBF_OK;
+}
+
+int pbf_predict(pbf_ctx* c, float dt) {
+    ENTER(c);
+    if (c->keyed) HIP_CK(c, hipMemsetAsync(c->cell_count, 0, (size_t)c->ncell * 4, c->stream));
+    if (c->n) {
+        PhaseScope ps(c, PH_PREDICT);
+        k_predict<<<nblocks(c->n), BLOCK, 0, c->stream>>>(
+            c->pos[c->cur], c->vel[c->cur], c->prd[c->prd_cur], c->key, c->cell_count, c->n, dt,
+            c->P.gravity[0], c->P.gravity[1], c->P.gravity[2], c->colliders, make_grid(c->P));
+        LAUNCH_CK(c);
+    }
+    c->keyed = true;
+    c->grid_valid = false;
+    return PBF_OK;
+}
+
+int pbf_build_grid(pbf_ctx* c) {
+    ENTER(c);
+    if (!c->keyed && c->n) {
+        k_rekey<<<nblocks(c->n), BLOCK, 0, c->stream>>>(c->prd[c->prd_cur], c->key, c->cell_count,
+                                                        c->n, make_grid(c->P));
+        LAUNCH_CK(c);
+    }
+    return sort_and_neighbors(c);
+}
+
+int pbf_compute_rest_density(pbf_ctx* c) {
+    ENTER(c);
+    if (c->P.rest_density_mode != PBF_RHO0_FIRST_FRAME_MEAN || !c->first_frame) return PBF_OK;
+    if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "pbf_build_grid must run first");
+    if (c->n) {
+        PhaseScope ps(c, PH_REST_DENSITY);
+        float* by_id = (float*)c->staging;
+        k_rest_density_terms<<<nblocks(c->n), BLOCK, 0, c->stream>>>(
+            c->pos[c->cur], c->id[c->cur], c->nbr, c->nbr_count, c->n, c->cap,
+            make_kern(c->P, 0.f), by_id);
+        k_rest_density_mean<<<1, 64, 0, c->stream>>>(by_id, c->n, c->rho0);
+        LAUNCH_CK(c);
+    }
+    c->first_frame = false;
+    return PBF_OK;
+}
+
+int pbf_solve(pbf_ctx* c, int32_t iterations, float dt) {
+    ENTER(c);
+    if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "pbf_build_grid must run first");
+    if (iterations <= 0) iterations = c->iterations;
+    if (!c->n) return PBF_OK;
+    const KernConsts kc = make_kern(c->P, dt);
+    const bool strict = c->P.arithmetic == PBF_ARITH_STRICT;
+    float3_ cmin = {c->P.container_min[0], c->P.container_min[1], c->P.container_min[2]};
+    float3_ cmax = {c->P.container_max[0], c->P.container_max[1], c->P.container_max[2]};
+    const uint32_t nb = nblocks(c->n);
+    for (int32_t it = 0; it < iterations; ++it) {
+        float4* x = c->prd[c->prd_cur];
+        float4* y = c->prd[(c->prd_cur + 1) % 3];
+        {
+            PhaseScope ps(c, PH_LAMBDA);
+            if (strict)
+                k_lambda<true><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count,
+                                                            c->n, c->cap, kc, c->rho0, c->dens, c->C);
+            else
+                k_lambda<false><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count,
+                                                             c->n, c->cap, kc, c->rho0, c->dens, c->C);
+        }
+        {
+            PhaseScope ps(c, PH_DELTA);
+            if (strict)
+                k_delta<true><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n, c->cap,
+                                                           kc, c->rho0, c->P.container_enabled,
+                                                           cmin, cmax);
+            else
+                k_delta<false><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n, c->cap,
+                                                            kc, c->rho0, c->P.container_enabled,
+                                                            cmin, cmax);
+        }
+        c->prd_cur = (c->prd_cur + 1) % 3;
+    }
+    LAUNCH_CK(c);
+    return PBF_OK;
+}
+
+int pbf_finalize(pbf_ctx* c, float dt) {
+    ENTER(c);
+    if (!c->n) return PBF_OK;
+    const uint32_t nb = nblocks(c->n);
+    {
+        PhaseScope ps(c, PH_FINALIZE);
+        k_finalize<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], c->vel[c->cur], c->prd[c->prd_cur],
+                                                c->n, dt);
+        LAUNCH_CK(c);
+    }
+    if (c->P.vorticity_eps != 0.f || c->P.xsph_c != 0.f) {
+        if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "viscosity needs the neighbour table");
+        PhaseScope ps(c, PH_VISCOSITY);
+        const KernConsts kc = make_kern(c->P, dt);
+        // the spare velocity copy (the one the next sort will overwrite) is the Jacobi target
+        float4* va = c->vel[c->cur];
+        float4* vb = c->vel[1 - c->cur];
+        if (c->P.vorticity_eps != 0.f) {
+            k_vorticity<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], va, c->nbr, c->nbr_count, c->n,
+                                                     c->cap, kc, c->omega);
+            k_vorticity_apply<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], va, c->omega, c->nbr,
+                                                           c->nbr_count, c->n, c->cap, kc, c->rho0,
+                                                           dt, c->P.vorticity_eps, vb);
+            float4* t = va; va = vb; vb = t;
+        }
+        if (c->P.xsph_c != 0.f) {
+            k_xsph<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], va, c->nbr, c->nbr_count, c->n,
+                                                c->cap, kc, c->rho0, c->P.xsph_c, vb);
+            float4* t = va; va = vb; vb = t;
+        }
+        if (va != c->vel[c->cur])
+            HIP_CK(c, hipMemcpyAsync(c->vel[c->cur], va, (size_t)c->n * 16, hipMemcpyDeviceToDevice,
+                                     c->stream));
+        LAUNCH_CK(c);
+    }
+    return PBF_OK;
+}
+
+int pbf_step(pbf_ctx* c, float dt) {
+    ENTER(c);
+    int rc = pbf_predict(c, dt);
+    if (rc) return rc;
+    rc = sort_and_neighbors(c);
+    if (rc) return rc;
+    if (c->first_frame) {
+        rc = pbf_compute_rest_density(c);
+        if (rc) return rc;
+        c->first_frame = false;
+    }
+    rc = pbf_solve(c, c->iterations, dt);
+    if (rc) return rc;
+    return pbf_finalize(c, dt);
+}
+
+int pbf_sync(pbf_ctx* c) {
+    ENTER(c);
+    return check_flags(c);
+}
+
+int pbf_download(pbf_ctx* c, float* pos, float* vel, float* pred) {
+    ENTER(c);
+    int rc = download3(c, c->pos[c->cur], pos);
+    if (rc) return rc;
+    rc = download3(c, c->vel[c->cur], vel);
+    if (rc) return rc;
+    rc = download3(c, c->prd[c->prd_cur], pred);
+    if (rc) return rc;
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    return PBF_OK;
+}
+
+int pbf_get_scalars(pbf_ctx* c, float* density, float* C, float* lambda) {
+    ENTER(c);
+    const uint32_t n = c->n;
+    if (!n) return PBF_OK;
+    // staging holds cap*16 B: three cap-float planes fit
+    float* st = (float*)c->staging;
+    float *o_d = st, *o_c = st + c->cap, *o_l = st + 2 * (size_t)c->cap;
+    k_unpack_scalars<<<nblocks(n), BLOCK, 0, c->stream>>>(c->dens, c->C, c->prd[c->prd_cur],
+                                                          c->id[c->cur], n, o_d, o_c, o_l);
+    LAUNCH_CK(c);
+    if (density) HIP_CK(c, hipMemcpyAsync(density, o_d, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (C) HIP_CK(c, hipMemcpyAsync(C, o_c, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (lambda) HIP_CK(c, hipMemcpyAsync(lambda, o_l, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    return PBF_OK;
+}
+
+int pbf_get_cells(pbf_ctx* c, int32_t* cell_xyz, uint32_t* cell_key_out, uint32_t* sorted_id,
+                  uint32_t* cell_start) {
+    ENTER(c);
+    if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "pbf_build_grid must run first");
+    const uint32_t n = c->n;
+    if (n && (cell_xyz || cell_key_out)) {
+        int32_t* xyz = (int32_t*)c->staging;           // n*12 B
+        uint32_t* key = (uint32_t*)c->staging + 3 * (size_t)c->cap;  // + n*4 B  (cap*16 total)
+        k_cells_by_id<<<nblocks(n), BLOCK, 0, c->stream>>>(c->prd[c->prd_cur], c->id[c->cur], n,
+                                                           make_grid(c->P), xyz, key);
+        LAUNCH_CK(c);
+        if (cell_xyz) HIP_CK(c, hipMemcpyAsync(cell_xyz, xyz, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
+        if (cell_key_out) HIP_CK(c, hipMemcpyAsync(cell_key_out, key, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (n && sorted_id)
+        HIP_CK(c, hipMemcpyAsync(sorted_id, c->id[c->cur], (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (cell_start)
+        HIP_CK(c, hipMemcpyAsync(cell_start, c->cell_start, ((size_t)c->ncell + 1) * 4,
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    return PBF_OK;
+}
+
+int pbf_get_neighbors(pbf_ctx* c, uint32_t* counts, uint32_t* neighbors, uint32_t stride) {
+    ENTER(c);
+    if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "pbf_build_grid must run first");
+    if (!counts || !neighbors || stride == 0) return fail(c, PBF_ERR_INVALID, "null output");
+    const uint32_t n = c->n;
+    if (!n) return PBF_OK;
+    uint32_t *d_counts = nullptr, *d_out = nullptr;
+    HIP_CK(c, dalloc(&d_counts, (size_t)n));
+    hipError_t e = dalloc(&d_out, (size_t)n * stride);
+    if (e != hipSuccess) {
+        (void)hipFree(d_counts);
+        return fail(c, PBF_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    (void)hipMemsetAsync(d_out, 0, (size_t)n * stride * 4, c->stream);
+    k_neighbors_by_id<<<nblocks(n), BLOCK, 0, c->stream>>>(c->nbr, c->nbr_count, c->id[c->cur], n,
+                                                           c->cap, stride, d_counts, d_out);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_counts, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(neighbors, d_out, (size_t)n * stride * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, PBF_ERR_HIP, std::string("get_neighbors: ") + hipGetErrorString(e));
+    return PBF_OK;
+}
+
+int pbf_get_stats(pbf_ctx* c, pbf_stats* out) {
+    ENTER(c);
+    if (!out) return fail(c, PBF_ERR_INVALID, "null output");
+    memset(out, 0, sizeof(*out));
+    out->n = c->n;
+    HIP_CK(c, hipMemcpyAsync(&out->rest_density, c->rho0, 4, hipMemcpyDeviceToHost, c->stream));
+    DevFlags f;
+    HIP_CK(c, hipMemcpyAsync(&f, c->flags, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+    uint32_t nb = nblocks(c->n);
+    if (nb > 1024) nb = 1024;
+    std::vector<StatPartial> parts(nb);
+    if (c->n) {
+        k_stats<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], c->vel[c->cur], c->C, c->nbr_count, c->n,
+                                             c->stat_partials);
+        LAUNCH_CK(c);
+        HIP_CK(c, hipMemcpyAsync(parts.data(), c->stat_partials, nb * sizeof(StatPartial),
+                                 hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    out->neighbor_overflow = f.neighbor_overflow;
+    double sa = 0, sc = 0, mx = 0, ms = 0, cx = 0, cy = 0, cz = 0, v2 = 0;
+    unsigned long long tot = 0;
+    for (auto& p : parts) {
+        sa += p.sum_abs_C;
+        sc += p.sum_C;
+        mx = p.max_abs_C > mx ? p.max_abs_C : mx;
+        ms += p.msum;
+        cx += p.mx;
+        cy += p.my;
+        cz += p.mz;
+        v2 = p.max_speed2 > v2 ? p.max_speed2 : v2;
+        tot += p.nbr_total;
+        out->nonfinite += p.nonfinite;
+        out->max_neighbor_count = p.max_nbr > out->max_neighbor_count ? p.max_nbr : out->max_neighbor_count;
+    }
+    if (c->n) {
+        out->mean_abs_C = sa / c->n;
+        out->mean_C = sc / c->n;
+        out->mean_neighbor_count = (double)tot / c->n;
+    }
+    out->max_abs_C = mx;
+    if (ms > 0) {
+        out->com[0] = cx / ms;
+        out->com[1] = cy / ms;
+        out->com[2] = cz / ms;
+    }
+    out->max_speed = sqrt(v2);
+    return PBF_OK;
+}
+
+int pbf_get_rest_density(pbf_ctx* c, float* out) {
+    ENTER(c);
+    if (!out) return fail(c, PBF_ERR_INVALID, "null output");
+    HIP_CK(c, hipMemcpyAsync(out, c->rho0, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    return PBF_OK;
+}
+
+uint32_t pbf_num_particles(const pbf_ctx* c) { return c ? c->n : 0; }
+
+int pbf_profile_enable(pbf_ctx* c, int enable) {
+    ENTER(c);
+    if (!enable) fold_spans(c);
+    c->prof = enable != 0;
+    return PBF_OK;
+}
+
+int pbf_profile_reset(pbf_ctx* c) {
+    ENTER(c);
+    fold_spans(c);
+    for (int i = 0; i < PH_COUNT; ++i) {
+        c->prof_ms[i] = 0;
+        c->prof_calls[i] = 0;
+    }
+    return PBF_OK;
+}
+
+int pbf_profile_read(pbf_ctx* c, double* ms, uint64_t* calls, uint32_t max_phases) {
+    ENTER(c);
+    fold_spans(c);
+    for (uint32_t i = 0; i < max_phases && i < PH_COUNT; ++i) {
+        if (ms) ms[i] = c->prof_ms[i];
+        if (calls) calls[i] = c->prof_calls[i];
+    }
+    return PBF_OK;
+}
+
+uint32_t pbf_num_phases(void) { return PH_COUNT; }
+
+const char* pbf_phase_name(uint32_t i) { return i < PH_COUNT ? kPhaseNames[i] : ""; }
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+"""Synthetic scenes of BASELINE.json's configs (all deterministic, fp32).
+
+Each generator restates the reference's own scene code and returns
+(params, pos[n,3] float32, uniform_mass, colliders).  No RNG: the jitter in
+GenerateFluidCube is dead code (reference Simulation.cpp:558-565).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .binding import (PBF_ARITH_STRICT, PBF_RHO0_FIRST_FRAME_MEAN, PBF_RHO0_FIXED, PbfParams,
+                      default_params, plane)
+
+F = np.float32
+REF_PI = F(3.1415926)  # reference common.h:8
+
+
+def sim_params_constants():
+    """Simulation::SetupSimParams derived constants (Simulation.cpp:315-326), in fp32:
+    h = 0.041528303, r = 0.012331058."""
+    mass = F(0.015)
+    n_kernel = F(20.0)
+    rho0 = F(1000.0)
+    volume = F(n_kernel * mass) / rho0
+    h = np.power(F(F(3.0) * volume) / F(F(4.0) * REF_PI), F(1.0) / F(3.0), dtype=F)
+    r = F(np.power(REF_PI / F(F(6.0) * n_kernel), F(1.0) / F(3.0), dtype=F) * h)
+    return F(h), F(r), F(volume), mass, rho0
+
+
+def reference_planes():
+    """The five plane colliders of the shipped scene (GLFWApp.cpp:177-191, Plane.cpp:49)."""
+    return [plane((0, 1, 0), 0.0), plane((1, 0, 0), -10.0), plane((-1, 0, 0), -10.0),
+            plane((0, 0, 1), -15.0), plane((0, 0, -1), 1.0)]
+
+
+def c1_lattice(nx=10, ny=100, nz=10, iterations=2):
+    """C1: GLFWApp::GenerateFluidParticles (GLFWApp.cpp:437-465): nx*ny*nz lattice at spacing
+    0.5, index k + nz*j + nz*ny*i, mass 0.1; h = 1, spacing-1 hash grid, five planes,
+    first-frame rest density, eps 1e-6, s_corr ~ dt^1.  The full scene is 10x100x10."""
+    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    x = F(0.0) + F(0.5) * i.astype(F)
+    y = F(0.5) + F(0.5) * j.astype(F)
+    z = F(-10.0) + F(0.5) * k.astype(F)
+    pos = np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(F)
+    p = default_params()
+    p.solver_iterations = iterations  # SetSolverIteration(2), GLFWApp.cpp:216
+    p.capacity = pos.shape[0]
+    return p, pos, 0.1, reference_planes()
+
+
+def tank_planes(lo, hi):
+    """Open-top tank as reference-style planes: hit iff dot(n, p) <= d."""
+    return [plane((0, 1, 0), lo[1]), plane((1, 0, 0), lo[0]), plane((-1, 0, 0), -hi[0]),
+            plane((0, 0, 1), lo[2]), plane((0, 0, -1), -hi[2])]
+
+
+def _grid_dim_for(extent_cells):
+    d = 16
+    while d < extent_cells + 2:
+        d *= 2
+    return d
+
+
+def dam_break(nx, ny, nz, iterations=4, tank_x_factor=2.5, xsph_c=0.0, vorticity_eps=0.0,
+              arithmetic=PBF_ARITH_STRICT, origin=(0.0, 0.0, 0.0), max_neighbors=96):
+    """C2-C5 family: nx*ny*nz block at the SetupSimParams spacing d = 2r filling the low-x end
+    of an open-top tank tank_x_factor times longer in x.  h = 0.041528303,
+    mass 0.015, rho0 = 1000 fixed, cell = h, s_corr ~ dt^3 as on the reference's GPU path
+    (cuda_simulation.cu:973); container clamp + planes keep the block in the tank.
+    These are build-side choices layered on the oracle (parity vs the oracle only)."""
+    h, r, _vol, mass, rho0 = sim_params_constants()
+    d = F(F(2.0) * r)
+    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    half = F(0.5) * d
+    x = F(origin[0]) + half + d * i.astype(F)
+    y = F(origin[1]) + half + d * j.astype(F)
+    z = F(origin[2]) + half + d * k.astype(F)
+    pos = np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(F)
+    lo = np.array(origin, dtype=F)
+    hi = lo + np.array([F(tank_x_factor) * d * F(nx), F(4.0) * d * F(ny), d * F(nz)], dtype=F)
+    p = default_params()
+    p.capacity = pos.shape[0]
+    p.max_neighbors = max_neighbors
+    p.effective_radius = float(h)
+    p.grid_spacing = float(h)
+    ext = (hi - lo) / h
+    p.grid_dim[:] = [_grid_dim_for(int(ext[0])), _grid_dim_for(int(min(ext[1], 2.0 * ny * d / h))),
+                     _grid_dim_for(int(ext[2]))]
+    p.epsilon = 100.0                 # SimParams.epsilon, Simulation.cpp:337
+    p.scorr_dt_power = 3              # cuda_simulation.cu:973
+    p.rest_density_mode = PBF_RHO0_FIXED
+    p.rest_density = float(rho0)      # Simulation.cpp:318
+    p.solver_iterations = iterations
+    p.arithmetic = arithmetic
+    p.container_enabled = 1
+    p.container_min[:] = [float(v) for v in lo]
+    p.container_max[:] = [float(hi[0]), 1.0e9, float(hi[2])]
+    p.xsph_c = xsph_c
+    p.vorticity_eps = vorticity_eps
+    return p, pos, float(mass), tank_planes(lo, hi)
+
+
+def c2_cube(iterations=4, **kw):
+    """C2: the README CUDA scene's particle count (40^3 = 64 000, Simulation.cpp:528-576)."""
+    return dam_break(40, 40, 40, iterations=iterations, **kw)
+
+
+def c3_block(iterations=4, **kw):
+    """C3: 100^3 = 1 000 000 particles."""
+    return dam_break(100, 100, 100, iterations=iterations, **kw)
+
+
+def fluid_cube_reference():
+    """Simulation::GenerateFluidCube (Simulation.cpp:528-576) exactly: 8*20^3 = 64 000 particles,
+    lattice i,j,k in [-n,n), centre (0,0.75,0), k fastest."""
+    _h, r, _v, mass, _rho = sim_params_constants()
+    d = F(F(2.0) * r)
+    n = int(F(0.5) / d)
+    rng = np.arange(-n, n)
+    i, j, k = np.meshgrid(rng, rng, rng, indexing="ij")
+    x = F(0.0) + d * i.astype(F)
+    y = F(0.75) + d * j.astype(F)
+    z = F(0.0) + d * k.astype(F)
+    return np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(F), float(mass)

@@ -1,0 +1,221 @@
+/*
+ * pbf.h -- C ABI of the MI355X-native Position-Based-Fluids sub-step.
+ *
+ * This is the drop-in boundary.  The reference has no plugin/FFI
+ * API; the cut is the level its own CUDA path already exposes as free host
+ * functions over raw device pointers (/root/reference/cuda_simulation.cuh:15-90)
+ * beneath the C++ class surface Simulation / ParticleSystem / NeighborSearch /
+ * ConstraintSolver (Simulation.h:50-77).  Each entry point below cites the
+ * reference interface it replaces.  Semantics follow the reference's OpenMP CPU
+ * path (Simulation::Step, Simulation.cpp:80-138), not its CUDA kernels.
+ *
+ * Conventions
+ *   - every function returns an int status (PBF_OK == 0); nothing aborts/exits
+ *     (the reference's getLastCudaError() exits the process, cuda_simulation.cu:393)
+ *   - one pbf_ctx == one device + one HIP stream; a ctx is not thread safe,
+ *     distinct ctxs are independent (no __constant__ singleton as in
+ *     cuda_simulation.cuh:13)
+ *   - host arrays are caller-owned, interleaved xyz float triples (the layout of
+ *     std::vector<glm::vec3>, Particle.h:56-61) indexed by ORIGINAL particle id
+ *   - step entry points are asynchronous on the ctx stream; pbf_sync / download /
+ *     get_* synchronise
+ *
+ * Plain C, no torch / HIP types in any signature.
+ */
+#ifndef PBF_H_
+#define PBF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBF_ABI_VERSION 1
+
+/* status codes */
+enum {
+    PBF_OK = 0,
+    PBF_ERR_INVALID = 1,       /* bad argument / bad state                             */
+    PBF_ERR_HIP = 2,           /* a HIP runtime call failed (see pbf_last_error)        */
+    PBF_ERR_CAPACITY = 3,      /* n exceeds ctx capacity                                */
+    PBF_ERR_NEIGHBOR_OVERFLOW = 4, /* a particle has more than max_neighbors neighbours */
+    PBF_ERR_NO_DEVICE = 5,     /* no HIP device / extension cannot run                  */
+    PBF_ERR_NOT_INITIALIZED = 6 /* Simulation::Step returns false (Simulation.cpp:82)   */
+};
+
+/* collider kinds: values of Collider::ColliderTypes (Collider.h:10-17) */
+enum {
+    PBF_COLLIDER_AABB = 2,
+    PBF_COLLIDER_PLANE = 4
+};
+
+/* One collider, copied by value into the ctx (the reference borrows raw
+ * Collider* from the app, Simulation.cpp:252-256).
+ *   PLANE: a = normal, d = offset; hit iff dot(a, p*) <= d   (CollisionDetection.cpp:62-67)
+ *   AABB : a = min, b = max;      hit iff strictly inside    (CollisionDetection.cpp:29-34) */
+typedef struct pbf_collider {
+    int32_t type;
+    float a[3];
+    float b[3];
+    float d;
+} pbf_collider;
+
+#define PBF_MAX_COLLIDERS 16
+
+/* rest-density modes */
+enum {
+    PBF_RHO0_FIRST_FRAME_MEAN = 0, /* Simulation::ComputeRestDensity, Simulation.cpp:273-300 */
+    PBF_RHO0_FIXED = 1             /* SetupSimParams rho0 = 1000, Simulation.cpp:318         */
+};
+
+/* arithmetic modes of the density-constraint kernels */
+enum {
+    PBF_ARITH_STRICT = 0, /* op-for-op restatement of SPHKernel.h (fp64 kernel evaluation,
+                             fp32 accumulation, reference summation order): bit-exact with
+                             the CPU oracle                                                   */
+    PBF_ARITH_FAST = 1    /* all-fp32 kernel evaluation (what the reference's own GPU path
+                             does, sph_kernel.cuh:6-52); within 1e-5 of the oracle           */
+};
+
+/* gradient kernel used for lambda / delta-p */
+enum {
+    PBF_GRAD_POLY6 = 0, /* what the reference actually calls (Simulation.cpp:657,665,706) */
+    PBF_GRAD_SPIKY = 1  /* SPHKernel::Spiky_W_Gradient (SPHKernel.h:78-97), never called
+                           by the reference                                               */
+};
+
+/* All solver parameters.  Replaces SimParams (Simulation.h:22-48) + SimWorldDesc
+ * (Simulation.h:14-20) + the constants hard-coded in Simulation::Step.  Defaults
+ * (pbf_default_params) reproduce the reference CPU path exactly. */
+typedef struct pbf_params {
+    uint32_t abi_version;       /* PBF_ABI_VERSION                                         */
+    uint32_t capacity;          /* max particles this ctx can hold (owned + ghosts)        */
+    uint32_t max_neighbors;     /* rows of the neighbour table (m_search_cache bound)      */
+    int32_t  grid_dim[3];       /* wrap-around cell grid; 64^3 at Simulation.cpp:46        */
+    float    grid_spacing;      /* m_grid_spacing = 1.f, NeighborSearch.cpp:17             */
+    float    effective_radius;  /* h; effective_radius = 1.f, Simulation.cpp:88            */
+    float    gravity[3];        /* (0, m_world_desc.gravity, 0), Simulation.cpp:16,592     */
+    float    epsilon;           /* 1.0e-6f, Simulation.cpp:644                             */
+    float    restitution;       /* 0.99f, Particle.cpp:333                                 */
+    double   scorr_k;           /* 0.1 (scorr = -0.1), Simulation.cpp:698                  */
+    float    scorr_dq;          /* 0.3f, Simulation.cpp:700                                */
+    int32_t  scorr_dt_power;    /* 1 on the CPU path (Simulation.cpp:702); the CUDA path
+                                   uses 3 (cuda_simulation.cu:973)                         */
+    int32_t  rest_density_mode; /* PBF_RHO0_*                                              */
+    float    rest_density;      /* value for PBF_RHO0_FIXED                                */
+    int32_t  solver_iterations; /* ConstraintSolver::m_solver_iteration, default 1
+                                   (ConstraintSolver.cpp:4)                                */
+    int32_t  arithmetic;        /* PBF_ARITH_*                                             */
+    int32_t  gradient_kernel;   /* PBF_GRAD_*                                              */
+    /* ---- build-side extensions, no reference counterpart (parity unpinned) ---- */
+    int32_t  container_enabled; /* per-iteration clamp of new positions into a tank       */
+    float    container_min[3];
+    float    container_max[3];
+    float    xsph_c;            /* XSPH viscosity coefficient (0 = off)                    */
+    float    vorticity_eps;     /* vorticity confinement strength (0 = off)                */
+} pbf_params;
+
+/* per-step health metrics (SURVEY.md section 5 "Metrics") */
+typedef struct pbf_stats {
+    uint32_t n;
+    uint32_t nonfinite;          /* particles with a non-finite position                   */
+    uint32_t neighbor_overflow;  /* particles that hit max_neighbors in the last search     */
+    uint32_t max_neighbor_count;
+    double   mean_neighbor_count;
+    double   mean_abs_C;         /* mean |rho_i/rho0 - 1| of the last solver iteration      */
+    double   max_abs_C;
+    double   mean_C;
+    double   com[3];             /* mass-weighted centre of mass                            */
+    double   max_speed;
+    float    rest_density;
+} pbf_stats;
+
+typedef struct pbf_ctx pbf_ctx;
+
+/* fills *p with the reference CPU path's constants */
+int pbf_default_params(pbf_params* p);
+
+/* Simulation::Initialize + ParticleSystem::SetupCUDAMemory + NeighborSearch::InitializeCUDA
+ * (Simulation.cpp:42-72, ParticleSystem.cpp:116-348, NeighborSearch.cpp:41-74):
+ * allocates every device array once.  device < 0 selects the current device. */
+int pbf_create(const pbf_params* params, int device, pbf_ctx** out);
+/* ParticleSystem::Release + NeighborSearch::Release (ParticleSystem.cpp:59-97, NeighborSearch.cpp:76-98) */
+int pbf_destroy(pbf_ctx* ctx);
+/* message of the last failure on this ctx (never NULL) */
+const char* pbf_last_error(const pbf_ctx* ctx);
+
+/* ParticleSystem::AllocateParticles + the cudaMemcpy block (ParticleSystem.cpp:99-103,188-260):
+ * pos/vel are n x 3 floats, mass n floats (NULL = uniform_mass for all).  Resets the
+ * first-frame flag (Simulation.cpp:17). */
+int pbf_upload(pbf_ctx* ctx, const float* pos, const float* vel, const float* mass,
+               float uniform_mass, uint32_t n);
+/* same, from device-resident buffers (inputs already in HBM) */
+int pbf_upload_device(pbf_ctx* ctx, const void* d_pos, const void* d_vel, const void* d_mass,
+                      float uniform_mass, uint32_t n);
+/* Simulation::AddCollider (Simulation.cpp:252-256); replaces the whole list, order kept */
+int pbf_set_colliders(pbf_ctx* ctx, const pbf_collider* colliders, uint32_t count);
+/* ConstraintSolver::setSolverIteration (ConstraintSolver.cpp:25-28) */
+int pbf_set_solver_iterations(pbf_ctx* ctx, int32_t iterations);
+/* Simulation::setGravity (Simulation.cpp:307-310) */
+int pbf_set_gravity(pbf_ctx* ctx, float gx, float gy, float gz);
+
+/* Simulation::PredictPositions + CollisionDetection (Simulation.cpp:578-599,723-751;
+ * ParticleSet::TestCollision/OnCollision, Particle.cpp:217-338); replaces integratePBD
+ * (cuda_simulation.cuh:21-27) */
+int pbf_predict(pbf_ctx* ctx, float dt);
+/* NeighborSearch::SpatialSearch (NeighborSearch.cpp:131-236); replaces calculate_hash +
+ * sort_particles + reorder_data (cuda_simulation.cuh:31-47): cell id -> counting sort ->
+ * prefix scan -> reorder -> neighbour table */
+int pbf_build_grid(pbf_ctx* ctx);
+/* Simulation::ComputeRestDensity (Simulation.cpp:273-300); no-op unless
+ * rest_density_mode == PBF_RHO0_FIRST_FRAME_MEAN and this is the first frame */
+int pbf_compute_rest_density(pbf_ctx* ctx);
+/* iterations x { ComputeDensity, ComputeLambdas, ComputeSPHParticlesCorrection,
+ * UpdatePredictPosition } (Simulation.cpp:112-118,607-721); replaces solve_sph_fluid
+ * (cuda_simulation.cuh:69-79).  iterations <= 0 uses the ctx's solver_iterations. */
+int pbf_solve(pbf_ctx* ctx, int32_t iterations, float dt);
+/* Simulation::ApplySolverResults -> ParticleSet::Update (Simulation.cpp:787-791,
+ * Particle.cpp:207-215), then XSPH viscosity / vorticity confinement when enabled */
+int pbf_finalize(pbf_ctx* ctx, float dt);
+/* Simulation::Step (Simulation.cpp:80-138) = predict, build_grid, [rest density],
+ * solve, finalize */
+int pbf_step(pbf_ctx* ctx, float dt);
+/* blocks until the ctx stream is idle; returns the sticky device-side error if any
+ * (PBF_ERR_NEIGHBOR_OVERFLOW) */
+int pbf_sync(pbf_ctx* ctx);
+
+/* copies state back in ORIGINAL id order; any pointer may be NULL.
+ * pos/vel/pred: n x 3 (m_positions, m_velocity, m_predict_positions == m_new_positions) */
+int pbf_download(pbf_ctx* ctx, float* pos, float* vel, float* pred);
+/* m_density, m_C, m_lambda (Particle.h:65-67) in original id order; NULLs allowed */
+int pbf_get_scalars(pbf_ctx* ctx, float* density, float* C, float* lambda);
+/* result of the last pbf_build_grid, for the bit-exact checks:
+ *   cell_xyz[n*3] : NeighborSearch::Flooring of every particle, by original id
+ *   cell_key[n]   : wrapped linear cell id, by original id
+ *   sorted_id[n]  : original id of the particle stored at each sorted slot
+ *   cell_start[num_cells+1] : exclusive prefix sum of cell occupancy */
+int pbf_get_cells(pbf_ctx* ctx, int32_t* cell_xyz, uint32_t* cell_key, uint32_t* sorted_id,
+                  uint32_t* cell_start);
+/* NeighborSearch::FetchNeighbors (NeighborSearch.cpp:238-241) for all particles:
+ * counts[n] and, for particle i, neighbors[i*stride + k] = ORIGINAL id of its k-th
+ * neighbour in the reference's m_search_cache order.  stride >= max count. */
+int pbf_get_neighbors(pbf_ctx* ctx, uint32_t* counts, uint32_t* neighbors, uint32_t stride);
+int pbf_get_stats(pbf_ctx* ctx, pbf_stats* out);
+/* current rest density (m_rest_density) */
+int pbf_get_rest_density(pbf_ctx* ctx, float* out);
+uint32_t pbf_num_particles(const pbf_ctx* ctx);
+
+/* per-phase device time of the kernels launched by this ctx, measured with HIP events on
+ * the ctx stream when enabled (replaces the ImGui chrono panel, Simulation.cpp:126-133).
+ * phase names: pbf_phase_name(i), i < pbf_num_phases(). ms[i] accumulates, calls[i] counts. */
+int pbf_profile_enable(pbf_ctx* ctx, int enable);
+int pbf_profile_reset(pbf_ctx* ctx);
+int pbf_profile_read(pbf_ctx* ctx, double* ms, uint64_t* calls, uint32_t max_phases);
+uint32_t pbf_num_phases(void);
+const char* pbf_phase_name(uint32_t i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBF_H_ */

@@ -1,0 +1,78 @@
+/*
+ * pbf_oracle.h -- CPU oracle: TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of the reference's OpenMP CPU path (Simulation::Step and
+ * the components it calls).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product (libpbf_hip.so) never does.
+ *
+ * Pinning status: SPHKernel and point/plane/AABB arithmetic are pinned against the
+ * reference's own sources compiled into oracle/_ref (see oracle/Makefile,
+ * tests/test_oracle_vs_ref.py); hash / flooring / derived constants are pinned by
+ * source-derived known answers; the reference holds no golden
+ * vectors or tests of its own, so the step loop as a whole is pinned only by
+ * those pieces plus NaiveSearch == SpatialSearch.  XSPH viscosity, vorticity
+ * confinement, the spiky-gradient option, the container clamp and scorr_dt_power
+ * != 1 have no reference implementation: PARITY UNPINNED for those.
+ */
+#ifndef PBF_ORACLE_H_
+#define PBF_ORACLE_H_
+
+#include <stdint.h>
+#include "pbf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_ctx orc_ctx;
+
+/* the reference CPU path's constants (same values as pbf_default_params) */
+int orc_default_params(pbf_params* p);
+int orc_create(const pbf_params* params, orc_ctx** out);
+int orc_destroy(orc_ctx* ctx);
+int orc_set_threads(orc_ctx* ctx, int num_threads); /* reference: num_threads(8) */
+int orc_upload(orc_ctx* ctx, const float* pos, const float* vel, const float* mass,
+               float uniform_mass, uint32_t n);
+int orc_set_colliders(orc_ctx* ctx, const pbf_collider* colliders, uint32_t count);
+int orc_set_solver_iterations(orc_ctx* ctx, int32_t iterations);
+int orc_set_gravity(orc_ctx* ctx, float gx, float gy, float gz);
+
+/* the sub-steps of Simulation::Step, one function per reference function */
+int orc_predict_positions(orc_ctx* ctx, float dt);       /* Simulation.cpp:578-599 */
+int orc_collision_detection(orc_ctx* ctx, float dt);     /* Simulation.cpp:723-751 */
+int orc_spatial_search(orc_ctx* ctx);                    /* NeighborSearch.cpp:131-236 */
+int orc_naive_search(orc_ctx* ctx);                      /* NeighborSearch.cpp:103-129 */
+int orc_compute_rest_density(orc_ctx* ctx);              /* Simulation.cpp:273-300 */
+int orc_compute_density(orc_ctx* ctx);                   /* Simulation.cpp:607-640 */
+int orc_compute_lambdas(orc_ctx* ctx);                   /* Simulation.cpp:642-679 */
+int orc_compute_correction(orc_ctx* ctx, float dt);      /* Simulation.cpp:681-712 */
+int orc_update_predict_position(orc_ctx* ctx);           /* Simulation.cpp:714-721 */
+int orc_apply_solver_results(orc_ctx* ctx, float dt);    /* Simulation.cpp:787-791 */
+int orc_step(orc_ctx* ctx, float dt);                    /* Simulation.cpp:80-138 */
+
+int orc_download(orc_ctx* ctx, float* pos, float* vel, float* pred, float* newp);
+int orc_get_scalars(orc_ctx* ctx, float* density, float* C, float* lambda);
+int orc_get_cells(orc_ctx* ctx, int32_t* cell_xyz, uint32_t* hash);
+uint64_t orc_neighbor_total(orc_ctx* ctx);
+uint32_t orc_neighbor_max(orc_ctx* ctx);
+int orc_get_neighbors(orc_ctx* ctx, uint32_t* counts, uint32_t* neighbors, uint32_t stride);
+int orc_get_stats(orc_ctx* ctx, pbf_stats* out);
+float orc_rest_density(orc_ctx* ctx);
+uint32_t orc_num_particles(orc_ctx* ctx);
+
+/* known-answer access to the leaf arithmetic */
+float orc_poly6_w(float distance, float h);                                   /* SPHKernel.h:9-30 */
+void orc_poly6_w_gradient(const float diff[3], float distance, float h, float out[3]); /* :32-54 */
+float orc_spiky_w(float distance, float h);                                   /* :56-75 */
+void orc_spiky_w_gradient(const float diff[3], float distance, float h, float out[3]); /* :78-97 */
+uint32_t orc_hash_value(int32_t x, int32_t y, int32_t z);      /* NeighborSearch.cpp:255-266 */
+void orc_flooring(const float p[3], float spacing, int32_t out[3]); /* NeighborSearch.cpp:243-252 */
+int orc_point_plane(const float p[3], const float n[3], float d);  /* CollisionDetection.cpp:62-67 */
+int orc_point_aabb(const float p[3], const float mn[3], const float mx[3]); /* :29-34 */
+/* Simulation::SetupSimParams derived constants (Simulation.cpp:315-326) */
+void orc_setup_sim_params(float* effective_radius, float* particle_radius, float* volume);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

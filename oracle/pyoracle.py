@@ -1,0 +1,241 @@
+"""ctypes door to the CPU oracle (oracle/libpbf_oracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The product package (fluidsimulation_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from fluidsimulation_amd.binding import (PBF_OK, PbfCollider, PbfParams, PbfStats,
+                                         collider_array)
+
+_DIR = Path(__file__).resolve().parent
+LIB_PATH = _DIR / "libpbf_oracle.so"
+REF_LIB_PATH = _DIR / "_ref" / "libpbf_ref.so"
+
+_lib = None
+_ref = None
+
+
+def build(force: bool = False):
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < (_DIR / "pbf_oracle.c").stat().st_mtime:
+        subprocess.run(["make", "-C", str(_DIR)], check=True, capture_output=True)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        build()
+    lib = C.CDLL(str(LIB_PATH))
+    vp = C.c_void_p
+    f3 = C.POINTER(C.c_float)
+    lib.orc_default_params.argtypes = [C.POINTER(PbfParams)]
+    lib.orc_create.argtypes = [C.POINTER(PbfParams), C.POINTER(vp)]
+    lib.orc_destroy.argtypes = [vp]
+    lib.orc_set_threads.argtypes = [vp, C.c_int]
+    lib.orc_upload.argtypes = [vp, vp, vp, vp, C.c_float, C.c_uint32]
+    lib.orc_set_colliders.argtypes = [vp, C.POINTER(PbfCollider), C.c_uint32]
+    lib.orc_set_solver_iterations.argtypes = [vp, C.c_int32]
+    lib.orc_set_gravity.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+    for name in ("orc_predict_positions", "orc_collision_detection", "orc_compute_correction",
+                 "orc_apply_solver_results", "orc_step"):
+        getattr(lib, name).argtypes = [vp, C.c_float]
+    for name in ("orc_spatial_search", "orc_naive_search", "orc_compute_rest_density",
+                 "orc_compute_density", "orc_compute_lambdas", "orc_update_predict_position"):
+        getattr(lib, name).argtypes = [vp]
+    lib.orc_download.argtypes = [vp, vp, vp, vp, vp]
+    lib.orc_get_scalars.argtypes = [vp, vp, vp, vp]
+    lib.orc_get_cells.argtypes = [vp, vp, vp]
+    lib.orc_neighbor_total.argtypes = [vp]
+    lib.orc_neighbor_total.restype = C.c_uint64
+    lib.orc_neighbor_max.argtypes = [vp]
+    lib.orc_neighbor_max.restype = C.c_uint32
+    lib.orc_get_neighbors.argtypes = [vp, vp, vp, C.c_uint32]
+    lib.orc_get_stats.argtypes = [vp, C.POINTER(PbfStats)]
+    lib.orc_rest_density.argtypes = [vp]
+    lib.orc_rest_density.restype = C.c_float
+    lib.orc_num_particles.argtypes = [vp]
+    lib.orc_num_particles.restype = C.c_uint32
+    lib.orc_poly6_w.argtypes = [C.c_float, C.c_float]
+    lib.orc_poly6_w.restype = C.c_float
+    lib.orc_spiky_w.argtypes = [C.c_float, C.c_float]
+    lib.orc_spiky_w.restype = C.c_float
+    lib.orc_poly6_w_gradient.argtypes = [f3, C.c_float, C.c_float, f3]
+    lib.orc_poly6_w_gradient.restype = None
+    lib.orc_spiky_w_gradient.argtypes = [f3, C.c_float, C.c_float, f3]
+    lib.orc_spiky_w_gradient.restype = None
+    lib.orc_hash_value.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.orc_hash_value.restype = C.c_uint32
+    lib.orc_flooring.argtypes = [f3, C.c_float, C.POINTER(C.c_int32)]
+    lib.orc_flooring.restype = None
+    lib.orc_point_plane.argtypes = [f3, f3, C.c_float]
+    lib.orc_point_aabb.argtypes = [f3, f3, f3]
+    lib.orc_setup_sim_params.argtypes = [f3, f3, f3]
+    lib.orc_setup_sim_params.restype = None
+    _lib = lib
+    return lib
+
+
+def load_ref():
+    """The reference's own leaf sources compiled into oracle/_ref (None if absent)."""
+    global _ref
+    if _ref is not None:
+        return _ref
+    if not REF_LIB_PATH.exists():
+        return None
+    lib = C.CDLL(str(REF_LIB_PATH))
+    f3 = C.POINTER(C.c_float)
+    lib.ref_poly6_w.argtypes = [C.c_float, C.c_float]
+    lib.ref_poly6_w.restype = C.c_float
+    lib.ref_spiky_w.argtypes = [C.c_float, C.c_float]
+    lib.ref_spiky_w.restype = C.c_float
+    lib.ref_poly6_w_gradient.argtypes = [f3, C.c_float, C.c_float, f3]
+    lib.ref_poly6_w_gradient.restype = None
+    lib.ref_spiky_w_gradient.argtypes = [f3, C.c_float, C.c_float, f3]
+    lib.ref_spiky_w_gradient.restype = None
+    lib.ref_point_plane.argtypes = [f3, f3, C.c_float]
+    lib.ref_point_aabb.argtypes = [f3, f3, f3]
+    lib.ref_glm_distance.argtypes = [f3, f3]
+    lib.ref_glm_distance.restype = C.c_float
+    lib.ref_glm_dot.argtypes = [f3, f3]
+    lib.ref_glm_dot.restype = C.c_float
+    lib.ref_glm_pow.argtypes = [C.c_double, C.c_int]
+    lib.ref_glm_pow.restype = C.c_double
+    _ref = lib
+    return lib
+
+
+def f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def default_params() -> PbfParams:
+    p = PbfParams()
+    load().orc_default_params(C.byref(p))
+    return p
+
+
+class Oracle:
+    """One orc_ctx; method names follow the reference's Simulation member functions."""
+
+    def __init__(self, params: PbfParams, threads: int = 8):
+        self.lib = load()
+        self.params = params.copy()
+        self._h = C.c_void_p()
+        rc = self.lib.orc_create(C.byref(self.params), C.byref(self._h))
+        if rc != PBF_OK:
+            raise RuntimeError(f"orc_create failed: {rc}")
+        self.lib.orc_set_threads(self._h, threads)
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h:
+            self.lib.orc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != PBF_OK:
+            raise RuntimeError(f"oracle error {rc}")
+
+    def upload(self, pos, vel=None, mass=None, uniform_mass: float = 1.0):
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+        n = pos.shape[0]
+        vel = None if vel is None else np.ascontiguousarray(vel, dtype=np.float32).reshape(n, 3)
+        mass = None if mass is None else np.ascontiguousarray(mass, dtype=np.float32).reshape(n)
+        self._ck(self.lib.orc_upload(self._h, _ptr(pos), _ptr(vel), _ptr(mass),
+                                     C.c_float(uniform_mass), n))
+        self.n = n
+
+    def set_colliders(self, cols):
+        self._ck(self.lib.orc_set_colliders(self._h, collider_array(cols), len(cols)))
+
+    def set_solver_iterations(self, it):
+        self._ck(self.lib.orc_set_solver_iterations(self._h, it))
+
+    def set_gravity(self, gx, gy, gz):
+        self._ck(self.lib.orc_set_gravity(self._h, gx, gy, gz))
+
+    def predict_positions(self, dt):
+        self._ck(self.lib.orc_predict_positions(self._h, C.c_float(dt)))
+
+    def collision_detection(self, dt):
+        self._ck(self.lib.orc_collision_detection(self._h, C.c_float(dt)))
+
+    def spatial_search(self):
+        self._ck(self.lib.orc_spatial_search(self._h))
+
+    def naive_search(self):
+        self._ck(self.lib.orc_naive_search(self._h))
+
+    def compute_rest_density(self):
+        self._ck(self.lib.orc_compute_rest_density(self._h))
+
+    def compute_density(self):
+        self._ck(self.lib.orc_compute_density(self._h))
+
+    def compute_lambdas(self):
+        self._ck(self.lib.orc_compute_lambdas(self._h))
+
+    def compute_correction(self, dt):
+        self._ck(self.lib.orc_compute_correction(self._h, C.c_float(dt)))
+
+    def update_predict_position(self):
+        self._ck(self.lib.orc_update_predict_position(self._h))
+
+    def apply_solver_results(self, dt):
+        self._ck(self.lib.orc_apply_solver_results(self._h, C.c_float(dt)))
+
+    def step(self, dt):
+        self._ck(self.lib.orc_step(self._h, C.c_float(dt)))
+
+    def download(self):
+        n = self.n
+        out = [np.empty((n, 3), np.float32) for _ in range(4)]
+        self._ck(self.lib.orc_download(self._h, *[_ptr(a) for a in out]))
+        return tuple(out)  # pos, vel, pred, new
+
+    def scalars(self):
+        n = self.n
+        out = [np.empty(n, np.float32) for _ in range(3)]
+        self._ck(self.lib.orc_get_scalars(self._h, *[_ptr(a) for a in out]))
+        return tuple(out)  # density, C, lambda
+
+    def cells(self):
+        xyz = np.empty((self.n, 3), np.int32)
+        h = np.empty(self.n, np.uint32)
+        self._ck(self.lib.orc_get_cells(self._h, _ptr(xyz), _ptr(h)))
+        return xyz, h
+
+    def neighbors(self, stride: int | None = None):
+        mx = int(self.lib.orc_neighbor_max(self._h))
+        stride = max(1, mx) if stride is None else stride
+        counts = np.empty(self.n, np.uint32)
+        nb = np.zeros((self.n, stride), np.uint32)
+        self._ck(self.lib.orc_get_neighbors(self._h, _ptr(counts), _ptr(nb), stride))
+        return counts, nb
+
+    def stats(self) -> PbfStats:
+        s = PbfStats()
+        self._ck(self.lib.orc_get_stats(self._h, C.byref(s)))
+        return s
+
+    def rest_density(self) -> float:
+        return float(self.lib.orc_rest_density(self._h))

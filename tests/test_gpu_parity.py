@@ -1,0 +1,310 @@
+"""GPU parity: the HIP path through the C ABI against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): cell indices, sorted order and neighbour sets bit-exact;
+positions/velocities within 1e-5 relative -- STRICT arithmetic is held to bit-exact,
+FAST arithmetic to the 1e-5 tolerance; 200-step density error and centre of mass within 1%.
+"""
+import numpy as np
+import pytest
+
+from fluidsimulation_amd import PbfContext, PbfError, aabb, plane, scenes
+from fluidsimulation_amd import binding as B
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+DT = 0.0005  # GLFWApp.cpp:393
+
+
+def make_pair(p, pos, mass, cols, vel=None, masses=None):
+    g = PbfContext(p, device=0)
+    o = pyoracle.Oracle(p)
+    for s in (g, o):
+        s.upload(pos, vel=vel, mass=masses, uniform_mass=mass)
+        s.set_colliders(cols)
+    return g, o
+
+
+def rel_inf(a, b):
+    den = max(float(np.abs(b).max()), 1e-30)
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) / den
+
+
+def jitter(pos, amp, seed=12345):
+    """xorshift32 jitter -- deterministic, no numpy RNG state involved."""
+    n = pos.size
+    x = np.uint32(seed)
+    out = np.empty(n, np.float32)
+    s = int(x)
+    for i in range(n):
+        s ^= (s << 13) & 0xFFFFFFFF
+        s ^= s >> 17
+        s ^= (s << 5) & 0xFFFFFFFF
+        out[i] = (s / 4294967296.0 - 0.5) * 2.0 * amp
+    return (pos + out.reshape(pos.shape)).astype(np.float32)
+
+
+# ------------------------------------------------------------------ sub-step by sub-step
+
+def test_predict_and_collide_bit_exact():
+    p, pos, mass, cols = scenes.c1_lattice(6, 10, 6)
+    rng = np.random.default_rng(7)
+    vel = rng.normal(0, 400.0, pos.shape).astype(np.float32)  # fast enough to cross planes
+    cols = cols + [aabb((0.6, 1.2, -9.6), (1.9, 2.7, -8.2))]
+    g, o = make_pair(p, pos, mass, cols, vel=vel)
+    g.predict(DT)
+    o.predict_positions(DT)
+    o.collision_detection(DT)
+    gp, gv, gq = g.download()
+    op, ov, oq, onew = o.download()
+    assert np.array_equal(gp, op)
+    assert np.array_equal(gv, ov)
+    assert np.array_equal(gq, oq) and np.array_equal(gq, onew)
+    # the collider branches were really taken
+    free = pos + np.float32(DT) * (vel + np.float32(DT) * np.float32(-9.8) * np.array([0, 1, 0], np.float32))
+    assert (np.abs(oq - free).max(axis=1) > 1e-3).sum() > 10
+
+
+def test_cells_sorted_order_neighbor_sets_bit_exact():
+    p, pos, mass, cols = scenes.c1_lattice(8, 16, 8)
+    pos = jitter(pos, 0.2)
+    g, o = make_pair(p, pos, mass, cols)
+    g.predict(DT)
+    g.build_grid()
+    o.predict_positions(DT)
+    o.collision_detection(DT)
+    o.spatial_search()
+    xyz, key, sid, start = g.cells()
+    oxyz, ohash = o.cells()
+    # cell indices == NeighborSearch::Flooring
+    assert np.array_equal(xyz, oxyz)
+    gd = np.array(list(p.grid_dim), np.int64)
+    w = np.mod(oxyz.astype(np.int64), gd)
+    okey = ((w[:, 0] * gd[1] + w[:, 1]) * gd[2] + w[:, 2]).astype(np.uint32)
+    assert np.array_equal(key, okey)
+    # sorted order == stable sort of the original indices by cell key
+    assert np.array_equal(sid, np.argsort(okey, kind="stable").astype(np.uint32))
+    # cell_start == exclusive prefix sum of the occupancy
+    occ = np.bincount(okey, minlength=start.size - 1)
+    assert np.array_equal(start, np.concatenate([[0], np.cumsum(occ)]).astype(np.uint32))
+    # neighbour lists: same members in the same order as m_search_cache
+    gc, gn = g.neighbors()
+    oc, on = o.neighbors(stride=int(p.max_neighbors))
+    assert np.array_equal(gc, oc)
+    assert np.array_equal(gn, on)
+    assert oc.max() > 20
+
+
+def test_neighbors_equal_brute_force():
+    """the reference's own cross-check idea: SpatialSearch == NaiveSearch as sets"""
+    p, pos, mass, cols = scenes.c1_lattice(5, 9, 5)
+    pos = jitter(pos, 0.24, seed=99)
+    g, o = make_pair(p, pos, mass, [])
+    g.build_grid()
+    o.naive_search()  # uses m_new_positions == positions here
+    gc, gn = g.neighbors()
+    oc, on = o.neighbors(stride=int(p.max_neighbors))
+    assert np.array_equal(gc, oc)
+    for i in range(pos.shape[0]):
+        assert set(gn[i, :gc[i]]) == set(on[i, :oc[i]])
+
+
+def test_rest_density_first_frame_bit_exact():
+    p, pos, mass, cols = scenes.c1_lattice(7, 11, 6)
+    g, o = make_pair(p, pos, mass, cols)
+    g.predict(DT); g.build_grid(); g.compute_rest_density()
+    o.predict_positions(DT); o.collision_detection(DT); o.spatial_search(); o.compute_rest_density()
+    assert g.rest_density() == o.rest_density()
+    assert 0.3 < g.rest_density() < 0.9
+
+
+def test_density_lambda_correction_bit_exact():
+    p, pos, mass, cols = scenes.c1_lattice(7, 12, 7)
+    pos = jitter(pos, 0.05, seed=3)
+    g, o = make_pair(p, pos, mass, cols)
+    g.predict(DT); g.build_grid(); g.compute_rest_density()
+    o.predict_positions(DT); o.collision_detection(DT); o.spatial_search(); o.compute_rest_density()
+    for it in range(2):
+        g.solve(DT, iterations=1)
+        o.compute_density(); o.compute_lambdas(); o.compute_correction(DT); o.update_predict_position()
+        gd, gC, gl = g.scalars()
+        od, oC, ol = o.scalars()
+        assert np.array_equal(gd, od), f"density differs at iteration {it}"
+        assert np.array_equal(gC, oC)
+        assert np.array_equal(gl, ol)
+        _, _, gq = g.download()
+        _, _, oq, onew = o.download()
+        assert np.array_equal(gq, oq) and np.array_equal(gq, onew)
+    g.finalize(DT)
+    o.apply_solver_results(DT)
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)
+
+
+# ------------------------------------------------------------------ whole steps
+
+@pytest.mark.parametrize("dims", [(10, 100, 10), (4, 4, 4), (1, 1, 1)])
+def test_c1_steps_bit_exact(dims):
+    """C1 (the README OpenMP scene, 10x100x10) and tiny/degenerate lattices: 5 sub-steps."""
+    p, pos, mass, cols = scenes.c1_lattice(*dims, iterations=2)
+    g, o = make_pair(p, pos, mass, cols)
+    for _ in range(5):
+        g.step(DT)
+        o.step(DT)
+    g.sync()
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op)
+    assert np.array_equal(gv, ov)
+    assert g.rest_density() == o.rest_density()
+
+
+def test_empty_input():
+    p, pos, mass, cols = scenes.c1_lattice(2, 2, 2)
+    g = PbfContext(p, device=0)
+    g.upload(np.zeros((0, 3), np.float32), uniform_mass=mass)
+    g.set_colliders(cols)
+    g.step(DT)
+    g.sync()
+    assert g.download()[0].shape == (0, 3)
+
+
+def test_per_particle_mass_and_velocity():
+    p, pos, mass, cols = scenes.c1_lattice(6, 8, 6, iterations=3)
+    rng = np.random.default_rng(11)
+    masses = rng.uniform(0.05, 0.2, pos.shape[0]).astype(np.float32)
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    g, o = make_pair(p, pos, mass, cols, vel=vel, masses=masses)
+    for _ in range(3):
+        g.step(DT); o.step(DT)
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)
+
+
+def test_c2_style_block_strict_and_fast():
+    """h = 0.0415 dam-break block (C2 family, reduced to 20^3), 4 iterations, container
+    clamp, fixed rho0: STRICT bit-exact; FAST within 1e-5 relative after one sub-step."""
+    p, pos, mass, cols = scenes.dam_break(20, 20, 20, iterations=4)
+    g, o = make_pair(p, pos, mass, cols)
+    for _ in range(3):
+        g.step(DT); o.step(DT)
+    g.sync()
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)
+
+    pf = p.copy()
+    pf.arithmetic = B.PBF_ARITH_FAST
+    gf = PbfContext(pf, device=0)
+    gf.upload(pos, uniform_mass=mass); gf.set_colliders(cols)
+    of = pyoracle.Oracle(p)
+    of.upload(pos, uniform_mass=mass); of.set_colliders(cols)
+    gf.step(DT); of.step(DT)
+    fp, fv, _ = gf.download()
+    op, ov, _, _ = of.download()
+    assert rel_inf(fp, op) <= 1e-5
+    assert rel_inf(fv, ov) <= 1e-5
+
+
+def test_c1_fast_single_step_tolerance():
+    p, pos, mass, cols = scenes.c1_lattice(10, 100, 10, iterations=2)
+    pf = p.copy()
+    pf.arithmetic = B.PBF_ARITH_FAST
+    g = PbfContext(pf, device=0)
+    g.upload(pos, uniform_mass=mass); g.set_colliders(cols)
+    o = pyoracle.Oracle(p)
+    o.upload(pos, uniform_mass=mass); o.set_colliders(cols)
+    g.step(DT); o.step(DT)
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert rel_inf(gp, op) <= 1e-5
+    assert rel_inf(gv, ov) <= 1e-5
+
+
+def test_200_steps_statistics_within_1pct():
+    """200 sub-steps of the C1 scene: mean/max density-constraint error and centre of mass
+    within 1 % of the oracle (FAST arithmetic; STRICT is bit-exact by the tests above)."""
+    p, pos, mass, cols = scenes.c1_lattice(10, 100, 10, iterations=2)
+    pf = p.copy()
+    pf.arithmetic = B.PBF_ARITH_FAST
+    g = PbfContext(pf, device=0)
+    g.upload(pos, uniform_mass=mass); g.set_colliders(cols)
+    o = pyoracle.Oracle(p)
+    o.upload(pos, uniform_mass=mass); o.set_colliders(cols)
+    for _ in range(200):
+        g.step(DT); o.step(DT)
+    g.sync()
+    gs, os_ = g.stats(), o.stats()
+    assert gs.nonfinite == 0 and os_.nonfinite == 0
+    assert abs(gs.mean_abs_C - os_.mean_abs_C) <= 0.01 * os_.mean_abs_C
+    assert abs(gs.max_abs_C - os_.max_abs_C) <= 0.01 * os_.max_abs_C
+    for a in range(3):
+        assert abs(gs.com[a] - os_.com[a]) <= 0.01 * max(abs(os_.com[a]), 1.0)
+
+
+def test_xsph_vorticity_bit_exact_vs_own_oracle():
+    """a20: no reference implementation (parity unpinned) -- checked against this repo's CPU
+    restatement of Macklin & Mueller 2013 eqs. 15-17."""
+    p, pos, mass, cols = scenes.dam_break(12, 12, 12, iterations=2, xsph_c=0.01, vorticity_eps=0.05)
+    rng = np.random.default_rng(5)
+    vel = rng.normal(0, 0.5, pos.shape).astype(np.float32)
+    g, o = make_pair(p, pos, mass, cols, vel=vel)
+    for _ in range(3):
+        g.step(DT); o.step(DT)
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)
+
+
+def test_spiky_gradient_option():
+    p, pos, mass, cols = scenes.dam_break(10, 10, 10, iterations=2)
+    p.gradient_kernel = B.PBF_GRAD_SPIKY
+    g, o = make_pair(p, pos, mass, cols)
+    for _ in range(2):
+        g.step(DT); o.step(DT)
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)
+
+
+def test_neighbor_overflow_is_loud():
+    p, pos, mass, cols = scenes.c1_lattice(6, 6, 6)
+    p.max_neighbors = 8
+    g = PbfContext(p, device=0)
+    g.upload(pos, uniform_mass=mass)
+    g.step(DT)
+    with pytest.raises(PbfError) as e:
+        g.sync()
+    assert e.value.code == B.PBF_ERR_NEIGHBOR_OVERFLOW
+
+
+def test_stats_match_oracle():
+    p, pos, mass, cols = scenes.c1_lattice(8, 20, 8, iterations=2)
+    g, o = make_pair(p, pos, mass, cols)
+    for _ in range(4):
+        g.step(DT); o.step(DT)
+    gs, os_ = g.stats(), o.stats()
+    assert gs.n == os_.n and gs.max_neighbor_count == os_.max_neighbor_count
+    assert gs.mean_neighbor_count == pytest.approx(os_.mean_neighbor_count, rel=1e-12)
+    assert gs.mean_abs_C == pytest.approx(os_.mean_abs_C, rel=1e-9)
+    assert gs.max_abs_C == pytest.approx(os_.max_abs_C, rel=1e-12)
+    assert list(gs.com) == pytest.approx(list(os_.com), rel=1e-9)
+    assert gs.max_speed == pytest.approx(os_.max_speed, rel=1e-9)
+
+
+def test_wraparound_grid_large_domain():
+    """particles spread over more cells than the grid holds: the wrapped grid aliases cells,
+    the distance test must still give the exact neighbour sets"""
+    p, pos, mass, cols = scenes.c1_lattice(6, 6, 6)
+    p.grid_dim[:] = [4, 5, 3]
+    pos = jitter(pos * np.float32(1.7), 0.3, seed=21)
+    g, o = make_pair(p, pos, mass, [])
+    g.build_grid()
+    o.spatial_search()
+    gc, gn = g.neighbors()
+    oc, on = o.neighbors(stride=int(p.max_neighbors))
+    assert np.array_equal(gc, oc)
+    for i in range(pos.shape[0]):
+        assert sorted(gn[i, :gc[i]]) == sorted(on[i, :oc[i]])

@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-substeps/s of the PBF sub-step on MI355X (BASELINE.json metric).
+
+A "step" is one PBF sub-step (predict -> collide -> grid/sort -> neighbour table ->
+4 x {density+lambda, delta-p} -> velocity update) over one synthetic dam-break block that is
+already resident in HBM.  N=1 runs config C3 (1M particles, 4 iterations).  Under
+torch.distributed (N>1) every rank owns an x-slab of the block (see fluidsimulation_amd/slab.py).
+
+Prints ONE JSON line (rank 0) with the `roofline` of the dominant kernel (device time from HIP
+events on the ctx stream) and the `cpu_baseline` (CPU oracle timed on this box's host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+DT = 0.0005
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# algorithmic bytes per particle, per launch of each phase
+ALGO_BYTES = {
+    "predict": 48 + 16 + 4,        # predict 48 + cell-id 16 + histogram 4
+    "sort": 2 + 80,                # scan ~2 + scatter/reorder 80
+    "lambda": 18,                  # density+lambda fused
+    "delta": 28,                   # delta-p + collide
+    "finalize": 48,
+}
+ALGO_BYTES_SUBSTEP_4IT = 382
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--block", type=int, nargs=3, default=None, help="nx ny nz of the particle block")
+    ap.add_argument("--iters", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle sub-steps to time (0 = skip)")
+    ap.add_argument("--cpu-block", type=int, nargs=3, default=None)
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(block, iters, steps):
+    """CPU oracle (a port of the reference's OpenMP path) on a bounded sample of the workload."""
+    from fluidsimulation_amd import scenes
+    from oracle import pyoracle
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    p, pos, mass, cols = scenes.dam_break(*block, iterations=iters)
+    o = pyoracle.Oracle(p, threads=threads)
+    o.upload(pos, uniform_mass=mass)
+    o.set_colliders(cols)
+    o.step(DT)  # warm-up (first frame)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o.step(DT)
+    dt = time.perf_counter() - t0
+    n = pos.shape[0]
+    return {
+        "value": n * steps / dt,
+        "unit": "particle-substeps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{steps} sub-steps of the {block[0]}x{block[1]}x{block[2]} dam-break block "
+                  f"({n} particles, {iters} iterations) after 1 warm-up, CPU oracle (oracle/pbf_oracle.c) "
+                  f"with {threads} OpenMP threads",
+    }
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the PBF path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from fluidsimulation_amd import PbfContext, scenes
+    from fluidsimulation_amd import binding as B
+
+    block = tuple(a.block) if a.block else (100, 100, 100)
+
+    if world == 1:
+        p, pos, mass, cols = scenes.dam_break(*block, iterations=a.iters)
+        ctx = PbfContext(p, device=local)
+        ctx.upload(pos, uniform_mass=mass)
+        ctx.set_colliders(cols)
+        n_total = pos.shape[0]
+        stepper = ctx.step
+        syncer = ctx.sync
+        workload = f"C3: {block[0]}x{block[1]}x{block[2]} dam-break block ({n_total} particles), {a.iters} solver iterations, dt=5e-4"
+        parallelism = "single GPU"
+    else:
+        from fluidsimulation_amd.slab import SlabSimulation
+        # weak scaling: every rank brings one block; slabs along x
+        p, pos, mass, cols = scenes.dam_break(block[0] * world, block[1], block[2], iterations=a.iters)
+        sim = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local)
+        n_total = pos.shape[0]
+        stepper = sim.step
+        syncer = sim.sync
+        ctx = sim.ctx
+        workload = (f"{block[0] * world}x{block[1]}x{block[2]} dam-break block ({n_total} particles) in "
+                    f"{world} x-slabs, {a.iters} solver iterations, dt=5e-4")
+        parallelism = f"slab{world}"
+
+    def barrier():
+        syncer()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        stepper(DT)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        stepper(DT)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stats = ctx.stats()
+
+    # per-kernel device time with HIP events on the ctx stream (a second pass: the event
+    # records sit between launches, so this pass is not the one `value` comes from)
+    roofline = None
+    phases = {}
+    if not a.no_profile:
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        ksteps = max(1, min(a.steps, 50))
+        for _ in range(ksteps):
+            stepper(DT)
+        barrier()
+        prof = ctx.profile_read()
+        ctx.profile_enable(False)
+        n_local = ctx.n
+        for name, (ms, calls) in prof.items():
+            if calls:
+                phases[name] = {"ms_per_launch": ms / calls, "launches_per_step": calls / ksteps,
+                                "ms_per_step": ms / ksteps}
+        cand = {k: v for k, v in phases.items() if k in ALGO_BYTES}
+        if cand:
+            dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
+            per_launch_s = cand[dom]["ms_per_launch"] * 1e-3
+            achieved = ALGO_BYTES[dom] * n_local / per_launch_s / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_particle": ALGO_BYTES[dom],
+                        "avg_launch_ms": cand[dom]["ms_per_launch"], "particles_per_launch": n_local}
+
+    if rank == 0:
+        value = n_total * a.steps / elapsed
+        cpu = None
+        if a.cpu_steps > 0:
+            cb = tuple(a.cpu_block) if a.cpu_block else (min(block[0], 60), min(block[1], 60), min(block[2], 60))
+            cpu = cpu_baseline(cb, a.iters, a.cpu_steps)
+        out = {
+            "metric": "particle-substeps/sec (PBF, 4 iters)",
+            "value": value,
+            "unit": "particle-substeps/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload, "particles": n_total, "iterations": a.iters,
+                       "arithmetic": "f32 state and accumulation, f64 SPH-kernel evaluation (as the reference CPU path)", "parallelism": parallelism,
+                       "substeps_per_s": a.steps / elapsed},
+            "hbm_roofline_frac_substep": ALGO_BYTES_SUBSTEP_4IT * value / (HBM_PEAK_GBS * 1e9 * world),
+            "roofline": roofline,
+            "phases": phases,
+            "cpu_baseline": cpu,
+            "health": {"nonfinite": stats.nonfinite, "neighbor_overflow": stats.neighbor_overflow,
+                       "max_neighbors": stats.max_neighbor_count,
+                       "mean_neighbors": stats.mean_neighbor_count, "mean_abs_C": stats.mean_abs_C},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

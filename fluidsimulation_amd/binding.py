@@ -27,8 +27,6 @@ PBF_COLLIDER_PLANE = 4  # Collider::ColliderTypes::PLANE
 
 PBF_RHO0_FIRST_FRAME_MEAN = 0
 PBF_RHO0_FIXED = 1
-PBF_ARITH_STRICT = 0
-PBF_ARITH_FAST = 1
 PBF_GRAD_POLY6 = 0
 PBF_GRAD_SPIKY = 1
 
@@ -54,7 +52,6 @@ class PbfParams(C.Structure):
         ("rest_density_mode", C.c_int32),
         ("rest_density", C.c_float),
         ("solver_iterations", C.c_int32),
-        ("arithmetic", C.c_int32),
         ("gradient_kernel", C.c_int32),
         ("container_enabled", C.c_int32),
         ("container_min", C.c_float * 3),
@@ -110,7 +107,6 @@ def default_params() -> PbfParams:
     p.rest_density_mode = PBF_RHO0_FIRST_FRAME_MEAN
     p.rest_density = 0.8                  # Simulation.cpp:18
     p.solver_iterations = 1               # ConstraintSolver.cpp:4
-    p.arithmetic = PBF_ARITH_STRICT
     p.gradient_kernel = PBF_GRAD_POLY6
     return p
 

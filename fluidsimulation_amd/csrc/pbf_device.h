@@ -1,11 +1,9 @@
 // pbf_device.h -- device-side arithmetic shared by the PBF kernels (gfx950).
 //
-// STRICT forms restate the reference CPU path op for op (fp64 SPH kernel evaluation with
+// These forms restate the reference CPU path op for op (fp64 SPH kernel evaluation with
 // the float literal pi, fp32 vectors with glm's (x*x + y*y) + z*z dot) so results are
 // bit-identical with the CPU oracle; the translation unit is compiled with
 // -ffp-contract=off and every fused multiply-add below is an explicit fma().
-// FAST forms evaluate the same kernels in fp32 (as the reference's own GPU path does,
-// sph_kernel.cuh:6-52).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,10 +24,6 @@ struct KernConsts {
     float g_coef;       // (float)(-945 / (32 pi h^9))
     float w_zero;       // Poly6_W(0, h)
     float w_dq;         // Poly6_W(scorr_dq * h, h)
-    float w_coef_f;     // fp32 copies for FAST
-    float spiky_coef_f;
-    float inv_w_dq;
-    float scorr_scale_f;  // -scorr_k * dt^p for FAST
     float epsilon;
     float dt;
     int32_t scorr_dt_power;
@@ -50,6 +44,16 @@ struct ColliderSet {
 struct float3_ {
     float x, y, z;
 };
+
+// XCD-aware workgroup order: hardware deals workgroups round-robin over the 8 XCDs (each
+// with a private 4 MiB L2), so blocks b and b+8 share an L2.  Remap so that each XCD walks
+// ONE contiguous eighth of the (cell-sorted) particle range: a block's neighbour gathers
+// then hit lines its own XCD already holds.  Bijective for any grid size.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
+    const uint32_t xcd = b & 7u, q = nb >> 3, r = nb & 7u;
+    const uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + (b >> 3);
+}
 
 // glm::dot on vec3 (reference include/glm/detail/func_geometric.inl:65-72)
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -122,31 +126,6 @@ __device__ __forceinline__ float scorr_strict(const KernConsts& k, float w) {
     double s = k.scorr_k * x;
     for (int t = 0; t < k.scorr_dt_power; ++t) s = s * (double)k.dt;
     return (float)s;
-}
-
-// ---- FAST fp32 forms (d2 = squared distance, no sqrt)
-__device__ __forceinline__ float poly6_fast(const KernConsts& k, float d2) {
-    float q = k.hh - d2;
-    q = q > 0.f ? q : 0.f;
-    return k.w_coef_f * (q * q * q);
-}
-
-__device__ __forceinline__ float grad_scalar_fast(const KernConsts& k, float d2) {
-    float q = k.hh - d2;
-    if (k.grad_kernel == PBF_GRAD_SPIKY) {
-        if (q <= 0.f || d2 <= 0.f) return 0.f;
-        float d = __builtin_sqrtf(d2);
-        float hq = k.h - d;
-        return k.spiky_coef_f * (hq * hq) / d;
-    }
-    q = q > 0.f ? q : 0.f;
-    return k.g_coef * (q * q);
-}
-
-__device__ __forceinline__ float scorr_fast(const KernConsts& k, float w) {
-    float x = w * k.inv_w_dq;
-    float x2 = x * x;
-    return k.scorr_scale_f * (x2 * x2);
 }
 
 }  // namespace pbf

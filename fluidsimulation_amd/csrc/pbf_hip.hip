@@ -348,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ 
                                                      uint32_t* __restrict__ nbr,
                                                      uint32_t* __restrict__ nbr_count,
                                                      DevFlags* __restrict__ flags) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     float4 xi = prd[i];
     int32_t cx = floor_cell(xi.x, G.spacing), cy = floor_cell(xi.y, G.spacing),
@@ -418,37 +418,31 @@ __global__ void k_rest_density_mean(const float* __restrict__ dens_by_id, uint32
 // share one pass over the neighbour row: rho_i and sum_j |gradW/rho0|^2 are independent.
 // lambda is written into prd[i].w (no reader uses .w during this kernel).
 
-template <bool STRICT>
+template <bool UNIFORM_MASS>
 __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __restrict__ pos,
                                                   const uint32_t* __restrict__ nbr,
                                                   const uint32_t* __restrict__ nbr_count,
                                                   uint32_t n, uint32_t cap, KernConsts kc,
                                                   const float* __restrict__ rho0_ptr,
+                                                  float uniform_mass,
                                                   float* __restrict__ dens_out,
                                                   float* __restrict__ C_out) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float rho0 = *rho0_ptr;
     const float inv_rho0 = 1.f / rho0;
     const float4 xi = prd[i];
-    float dens = pos[i].w * kc.w_zero;
+    float dens = (UNIFORM_MASS ? uniform_mass : pos[i].w) * kc.w_zero;
     float grad_sum = 0.f;  // self term: |(1/rho0) gradW(0)|^2 == 0 (Simulation.cpp:657-658)
     const uint32_t cnt = nbr_count[i];
     for (uint32_t k = 0; k < cnt; ++k) {
         uint32_t j = nbr[(size_t)k * cap + i];
         float4 xj = prd[j];
-        float mj = pos[j].w;
+        float mj = UNIFORM_MASS ? uniform_mass : pos[j].w;
         float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-        float d2 = dot3(dx, dy, dz, dx, dy, dz);
-        float w, gs;
-        if (STRICT) {
-            float distance = sqrtf(d2);
-            w = poly6_strict(kc, distance);
-            gs = grad_scalar_strict(kc, distance);
-        } else {
-            w = poly6_fast(kc, d2);
-            gs = grad_scalar_fast(kc, d2);
-        }
+        float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        float w = poly6_strict(kc, distance);
+        float gs = grad_scalar_strict(kc, distance);
         dens += mj * w;
         // gradientC_j = (1/rho0) * (gs * diff); sum += dot(gC, gC)
         float gx = inv_rho0 * (gs * dx), gy = inv_rho0 * (gs * dy), gz = inv_rho0 * (gs * dz);
@@ -466,7 +460,6 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __r
 // Jacobi hand-over copy directly (UpdatePredictPosition, :714-721), plus the build-side
 // container clamp.  Accumulates onto new_i in neighbour-row order like the reference.
 
-template <bool STRICT>
 __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
                                                  float4* __restrict__ prd_out,
                                                  const uint32_t* __restrict__ nbr,
@@ -474,7 +467,7 @@ __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
                                                  uint32_t n, uint32_t cap, KernConsts kc,
                                                  const float* __restrict__ rho0_ptr,
                                                  int container, float3_ cmin, float3_ cmax) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float inv_rho0 = 1.f / *rho0_ptr;
     const float4 xi = prd[i];
@@ -484,16 +477,9 @@ __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
         uint32_t j = nbr[(size_t)k * cap + i];
         float4 xj = prd[j];
         float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-        float d2 = dot3(dx, dy, dz, dx, dy, dz);
-        float sc, gs;
-        if (STRICT) {
-            float distance = sqrtf(d2);
-            sc = scorr_strict(kc, poly6_strict(kc, distance));
-            gs = grad_scalar_strict(kc, distance);
-        } else {
-            sc = scorr_fast(kc, poly6_fast(kc, d2));
-            gs = grad_scalar_fast(kc, d2);
-        }
+        float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        float sc = scorr_strict(kc, poly6_strict(kc, distance));
+        float gs = grad_scalar_strict(kc, distance);
         // result = (1/rho0) * (lambda_i + lambda_j + (float)scorr) * gradW
         float s = inv_rho0 * (xi.w + xj.w + sc);
         nx += s * (gs * dx);
@@ -534,7 +520,7 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(const float4* __restrict__ 
                                                      const uint32_t* __restrict__ nbr_count,
                                                      uint32_t n, uint32_t cap, KernConsts kc,
                                                      float4* __restrict__ omega) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float4 pi = pos[i];
     const float4 vi = vel[i];
@@ -561,7 +547,7 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity_apply(
     const float4* __restrict__ omega, const uint32_t* __restrict__ nbr,
     const uint32_t* __restrict__ nbr_count, uint32_t n, uint32_t cap, KernConsts kc,
     const float* __restrict__ rho0_ptr, float dt, float eps_v, float4* __restrict__ vel_out) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float inv_rho0 = 1.f / *rho0_ptr;
     const float4 pi = pos[i];
@@ -601,7 +587,7 @@ __global__ __launch_bounds__(BLOCK) void k_xsph(const float4* __restrict__ pos,
                                                 uint32_t n, uint32_t cap, KernConsts kc,
                                                 const float* __restrict__ rho0_ptr, float c,
                                                 float4* __restrict__ vel_out) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float inv_rho0 = 1.f / *rho0_ptr;
     const float4 pi = pos[i];
@@ -758,6 +744,8 @@ struct pbf_ctx {
     StatPartial* stat_partials = nullptr;
     ColliderSet colliders;
     bool first_frame = true;
+    bool uniform = false;      // every particle has uniform_mass (no per-neighbour mass gather)
+    float uniform_mass = 0.f;
     bool keyed = false;  // histogram of the live prd already accumulated by k_predict
     bool grid_valid = false;
     int32_t iterations = 1;
@@ -818,12 +806,6 @@ KernConsts make_kern(const pbf_params& P, float dt) {
         double d = (double)dq, q = k.h2 - d * d;
         k.w_dq = (dq >= 0 && dq <= k.h) ? (float)(k.w_coef * (q * q * q)) : 0.f;
     }
-    k.w_coef_f = (float)k.w_coef;
-    k.spiky_coef_f = (float)k.spiky_coef;
-    k.inv_w_dq = k.w_dq != 0.f ? 1.f / k.w_dq : 0.f;
-    double s = -P.scorr_k;
-    for (int t = 0; t < P.scorr_dt_power; ++t) s *= (double)dt;
-    k.scorr_scale_f = (float)s;
     k.epsilon = P.epsilon;
     k.dt = dt;
     k.scorr_dt_power = P.scorr_dt_power;
@@ -902,7 +884,6 @@ int validate_params(const pbf_params& P, std::string& why) {
     if (!(P.grid_spacing > 0.f) || !(P.effective_radius > 0.f)) { why = "grid_spacing and effective_radius must be > 0"; return PBF_ERR_INVALID; }
     if (P.effective_radius > P.grid_spacing) { why = "effective_radius must not exceed grid_spacing (27-cell sweep)"; return PBF_ERR_INVALID; }
     if (P.solver_iterations < 0 || P.scorr_dt_power < 0 || P.scorr_dt_power > 8) { why = "bad iteration / scorr_dt_power"; return PBF_ERR_INVALID; }
-    if (P.arithmetic != PBF_ARITH_STRICT && P.arithmetic != PBF_ARITH_FAST) { why = "bad arithmetic mode"; return PBF_ERR_INVALID; }
     if (P.gradient_kernel != PBF_GRAD_POLY6 && P.gradient_kernel != PBF_GRAD_SPIKY) { why = "bad gradient_kernel"; return PBF_ERR_INVALID; }
     if (P.rest_density_mode != PBF_RHO0_FIRST_FRAME_MEAN && P.rest_density_mode != PBF_RHO0_FIXED) { why = "bad rest_density_mode"; return PBF_ERR_INVALID; }
     return PBF_OK;
@@ -1007,7 +988,6 @@ int pbf_default_params(pbf_params* p) {
     p->rest_density_mode = PBF_RHO0_FIRST_FRAME_MEAN;
     p->rest_density = 0.8f;    // Simulation.cpp:18
     p->solver_iterations = 1;  // ConstraintSolver.cpp:4
-    p->arithmetic = PBF_ARITH_STRICT;
     p->gradient_kernel = PBF_GRAD_POLY6;
     return PBF_OK;
 }
@@ -1139,6 +1119,8 @@ static int upload_common(pbf_ctx* c, const float* d_pos, const float* d_vel, con
     HIP_CK(c, hipMemsetAsync(c->flags, 0, sizeof(DevFlags), c->stream));
     HIP_CK(c, hipStreamSynchronize(c->stream));
     c->n = n;
+    c->uniform = (d_mass == nullptr);
+    c->uniform_mass = uniform_mass;
     c->first_frame = true;
     c->keyed = false;
     c->grid_valid = false;
@@ -1256,7 +1238,6 @@ int pbf_solve(pbf_ctx* c, int32_t iterations, float dt) {
     if (iterations <= 0) iterations = c->iterations;
     if (!c->n) return PBF_OK;
     const KernConsts kc = make_kern(c->P, dt);
-    const bool strict = c->P.arithmetic == PBF_ARITH_STRICT;
     float3_ cmin = {c->P.container_min[0], c->P.container_min[1], c->P.container_min[2]};
     float3_ cmax = {c->P.container_max[0], c->P.container_max[1], c->P.container_max[2]};
     const uint32_t nb = nblocks(c->n);
@@ -1265,23 +1246,19 @@ int pbf_solve(pbf_ctx* c, int32_t iterations, float dt) {
         float4* y = c->prd[(c->prd_cur + 1) % 3];
         {
             PhaseScope ps(c, PH_LAMBDA);
-            if (strict)
+            if (c->uniform)
                 k_lambda<true><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count,
-                                                            c->n, c->cap, kc, c->rho0, c->dens, c->C);
+                                                            c->n, c->cap, kc, c->rho0,
+                                                            c->uniform_mass, c->dens, c->C);
             else
                 k_lambda<false><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count,
-                                                             c->n, c->cap, kc, c->rho0, c->dens, c->C);
+                                                             c->n, c->cap, kc, c->rho0,
+                                                             c->uniform_mass, c->dens, c->C);
         }
         {
             PhaseScope ps(c, PH_DELTA);
-            if (strict)
-                k_delta<true><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n, c->cap,
-                                                           kc, c->rho0, c->P.container_enabled,
-                                                           cmin, cmax);
-            else
-                k_delta<false><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n, c->cap,
-                                                            kc, c->rho0, c->P.container_enabled,
-                                                            cmin, cmax);
+            k_delta<<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n, c->cap, kc,
+                                                 c->rho0, c->P.container_enabled, cmin, cmax);
         }
         c->prd_cur = (c->prd_cur + 1) % 3;
     }

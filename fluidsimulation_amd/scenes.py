@@ -8,8 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .binding import (PBF_ARITH_STRICT, PBF_RHO0_FIRST_FRAME_MEAN, PBF_RHO0_FIXED, PbfParams,
-                      default_params, plane)
+from .binding import PBF_RHO0_FIXED, default_params, plane
 
 F = np.float32
 REF_PI = F(3.1415926)  # reference common.h:8
@@ -62,7 +61,7 @@ def _grid_dim_for(extent_cells):
 
 
 def dam_break(nx, ny, nz, iterations=4, tank_x_factor=2.5, xsph_c=0.0, vorticity_eps=0.0,
-              arithmetic=PBF_ARITH_STRICT, origin=(0.0, 0.0, 0.0), max_neighbors=96):
+              origin=(0.0, 0.0, 0.0), max_neighbors=96):
     """C2-C5 family: nx*ny*nz block at the SetupSimParams spacing d = 2r filling the low-x end
     of an open-top tank tank_x_factor times longer in x.  h = 0.041528303,
     mass 0.015, rho0 = 1000 fixed, cell = h, s_corr ~ dt^3 as on the reference's GPU path
@@ -91,7 +90,6 @@ def dam_break(nx, ny, nz, iterations=4, tank_x_factor=2.5, xsph_c=0.0, vorticity
     p.rest_density_mode = PBF_RHO0_FIXED
     p.rest_density = float(rho0)      # Simulation.cpp:318
     p.solver_iterations = iterations
-    p.arithmetic = arithmetic
     p.container_enabled = 1
     p.container_min[:] = [float(v) for v in lo]
     p.container_max[:] = [float(hi[0]), 1.0e9, float(hi[2])]

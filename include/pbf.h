@@ -69,15 +69,6 @@ enum {
     PBF_RHO0_FIXED = 1             /* SetupSimParams rho0 = 1000, Simulation.cpp:318         */
 };
 
-/* arithmetic modes of the density-constraint kernels */
-enum {
-    PBF_ARITH_STRICT = 0, /* op-for-op restatement of SPHKernel.h (fp64 kernel evaluation,
-                             fp32 accumulation, reference summation order): bit-exact with
-                             the CPU oracle                                                   */
-    PBF_ARITH_FAST = 1    /* all-fp32 kernel evaluation (what the reference's own GPU path
-                             does, sph_kernel.cuh:6-52); within 1e-5 of the oracle           */
-};
-
 /* gradient kernel used for lambda / delta-p */
 enum {
     PBF_GRAD_POLY6 = 0, /* what the reference actually calls (Simulation.cpp:657,665,706) */
@@ -106,7 +97,6 @@ typedef struct pbf_params {
     float    rest_density;      /* value for PBF_RHO0_FIXED                                */
     int32_t  solver_iterations; /* ConstraintSolver::m_solver_iteration, default 1
                                    (ConstraintSolver.cpp:4)                                */
-    int32_t  arithmetic;        /* PBF_ARITH_*                                             */
     int32_t  gradient_kernel;   /* PBF_GRAD_*                                              */
     /* ---- build-side extensions, no reference counterpart (parity unpinned) ---- */
     int32_t  container_enabled; /* per-iteration clamp of new positions into a tank       */

@@ -265,7 +265,6 @@ int orc_default_params(pbf_params* p) {
     p->rest_density_mode = PBF_RHO0_FIRST_FRAME_MEAN;      /* Simulation.cpp:103-107 */
     p->rest_density = 0.8f;                                /* Simulation.cpp:18 */
     p->solver_iterations = 1;                              /* ConstraintSolver.cpp:4 */
-    p->arithmetic = PBF_ARITH_STRICT;
     p->gradient_kernel = PBF_GRAD_POLY6;
     return PBF_OK;
 }

@@ -1,8 +1,9 @@
 """GPU parity: the HIP path through the C ABI against the CPU oracle on the same inputs.
 
 Bars (BASELINE.json north_star): cell indices, sorted order and neighbour sets bit-exact;
-positions/velocities within 1e-5 relative -- STRICT arithmetic is held to bit-exact,
-FAST arithmetic to the 1e-5 tolerance; 200-step density error and centre of mass within 1%.
+positions/velocities within 1e-5 relative in fp32 -- the kernels restate the reference's
+arithmetic op for op, so the tests hold them to bit-exact; 200-step density error and
+centre of mass within 1%.
 """
 import numpy as np
 import pytest
@@ -183,9 +184,10 @@ def test_per_particle_mass_and_velocity():
     assert np.array_equal(gp, op) and np.array_equal(gv, ov)
 
 
-def test_c2_style_block_strict_and_fast():
+def test_c2_style_block_bit_exact():
     """h = 0.0415 dam-break block (C2 family, reduced to 20^3), 4 iterations, container
-    clamp, fixed rho0: STRICT bit-exact; FAST within 1e-5 relative after one sub-step."""
+    clamp, fixed rho0, s_corr ~ dt^3: bit-exact with the oracle after 3 sub-steps; a fortiori
+    within the 1e-5 relative bar of north_star."""
     p, pos, mass, cols = scenes.dam_break(20, 20, 20, iterations=4)
     g, o = make_pair(p, pos, mass, cols)
     for _ in range(3):
@@ -194,45 +196,26 @@ def test_c2_style_block_strict_and_fast():
     gp, gv, _ = g.download()
     op, ov, _, _ = o.download()
     assert np.array_equal(gp, op) and np.array_equal(gv, ov)
-
-    pf = p.copy()
-    pf.arithmetic = B.PBF_ARITH_FAST
-    gf = PbfContext(pf, device=0)
-    gf.upload(pos, uniform_mass=mass); gf.set_colliders(cols)
-    of = pyoracle.Oracle(p)
-    of.upload(pos, uniform_mass=mass); of.set_colliders(cols)
-    gf.step(DT); of.step(DT)
-    fp, fv, _ = gf.download()
-    op, ov, _, _ = of.download()
-    assert rel_inf(fp, op) <= 1e-5
-    assert rel_inf(fv, ov) <= 1e-5
+    assert rel_inf(gp, op) <= 1e-5 and rel_inf(gv, ov) <= 1e-5
 
 
-def test_c1_fast_single_step_tolerance():
-    p, pos, mass, cols = scenes.c1_lattice(10, 100, 10, iterations=2)
-    pf = p.copy()
-    pf.arithmetic = B.PBF_ARITH_FAST
-    g = PbfContext(pf, device=0)
-    g.upload(pos, uniform_mass=mass); g.set_colliders(cols)
-    o = pyoracle.Oracle(p)
-    o.upload(pos, uniform_mass=mass); o.set_colliders(cols)
+def test_c2_64k_single_step():
+    """C2 at full size (40^3 = 64 000 particles, 4 iterations): one sub-step bit-exact."""
+    p, pos, mass, cols = scenes.c2_cube()
+    g, o = make_pair(p, pos, mass, cols)
     g.step(DT); o.step(DT)
+    g.sync()
     gp, gv, _ = g.download()
     op, ov, _, _ = o.download()
-    assert rel_inf(gp, op) <= 1e-5
-    assert rel_inf(gv, ov) <= 1e-5
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)
 
 
 def test_200_steps_statistics_within_1pct():
-    """200 sub-steps of the C1 scene: mean/max density-constraint error and centre of mass
-    within 1 % of the oracle (FAST arithmetic; STRICT is bit-exact by the tests above)."""
+    """200 sub-steps of the C1 scene (10 000 particles, 2 iterations): mean/max
+    density-constraint error and centre of mass within 1 % of the oracle (north_star bar) --
+    and, because the arithmetic is restated op for op, the state itself is still bit-exact."""
     p, pos, mass, cols = scenes.c1_lattice(10, 100, 10, iterations=2)
-    pf = p.copy()
-    pf.arithmetic = B.PBF_ARITH_FAST
-    g = PbfContext(pf, device=0)
-    g.upload(pos, uniform_mass=mass); g.set_colliders(cols)
-    o = pyoracle.Oracle(p)
-    o.upload(pos, uniform_mass=mass); o.set_colliders(cols)
+    g, o = make_pair(p, pos, mass, cols)
     for _ in range(200):
         g.step(DT); o.step(DT)
     g.sync()
@@ -242,6 +225,9 @@ def test_200_steps_statistics_within_1pct():
     assert abs(gs.max_abs_C - os_.max_abs_C) <= 0.01 * os_.max_abs_C
     for a in range(3):
         assert abs(gs.com[a] - os_.com[a]) <= 0.01 * max(abs(os_.com[a]), 1.0)
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)
 
 
 def test_xsph_vorticity_bit_exact_vs_own_oracle():

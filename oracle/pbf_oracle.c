@@ -230,9 +230,11 @@ int orc_point_aabb(const float p[3], const float mn[3], const float mx[3]) {
 
 /* Simulation::SetupSimParams, Simulation.cpp:315-326 */
 void orc_setup_sim_params(float* effective_radius, float* particle_radius, float* volume) {
-    const float particle_mass = 0.015f;
-    const float n_kernel_particles = 20.f;
-    const float rest_density = 1000.f;
+    /* volatile: evaluate powf at run time with libm, as the reference binary does, instead of
+     * letting the compiler fold it (the folded value differs from glibc's by one ulp in r) */
+    volatile float particle_mass = 0.015f;
+    volatile float n_kernel_particles = 20.f;
+    volatile float rest_density = 1000.f;
     float v = n_kernel_particles * particle_mass / rest_density;
     float h = powf(((3.0f * v) / (4.0f * REF_PI)), 1.0f / 3.0f);
     float r = powf((REF_PI / (6.0f * n_kernel_particles)), 1.0f / 3.0f) * h;

@@ -1,0 +1,81 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/pbf.h declares; the
+struct mirrors agree; and the product path fails loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+from fluidsimulation_amd import binding as B
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = (ROOT / "include" / "pbf.h").read_text()
+
+
+def declared_symbols():
+    return sorted(set(re.findall(r"\b(pbf_[a-z0-9_]+)\s*\(", HEADER)))
+
+
+def test_header_symbols_are_listed_in_binding():
+    assert declared_symbols() == sorted(B.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    assert B.LIB_PATH.exists(), "libpbf_hip.so missing: run __graft_entry__.build()"
+    lib = C.CDLL(str(B.LIB_PATH))
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"{s} not exported"
+
+
+def test_default_params_same_in_c_and_python():
+    lib = B.load_library()
+    p = B.PbfParams()
+    assert lib.pbf_default_params(C.byref(p)) == B.PBF_OK
+    assert bytes(p) == bytes(B.default_params())
+    assert lib.pbf_default_params(None) == B.PBF_ERR_INVALID
+
+
+def test_phase_names():
+    lib = B.load_library()
+    names = [lib.pbf_phase_name(i).decode() for i in range(lib.pbf_num_phases())]
+    assert names[:3] == ["predict", "sort", "neighbors"] and "lambda" in names and "delta" in names
+
+
+def test_create_rejects_bad_params_before_touching_a_device():
+    lib = B.load_library()
+    h = C.c_void_p()
+    p = B.default_params()
+    p.capacity = 0
+    assert lib.pbf_create(C.byref(p), -1, C.byref(h)) == B.PBF_ERR_INVALID
+    p = B.default_params()
+    p.capacity = 16
+    p.grid_dim[1] = 2
+    assert lib.pbf_create(C.byref(p), -1, C.byref(h)) == B.PBF_ERR_INVALID
+    assert b"grid_dim" in lib.pbf_last_error(None)
+    p = B.default_params()
+    p.capacity = 16
+    p.effective_radius = 2.0   # wider than a cell: the 27-cell sweep would miss neighbours
+    assert lib.pbf_create(C.byref(p), -1, C.byref(h)) == B.PBF_ERR_INVALID
+    p = B.default_params()
+    p.capacity = 16
+    p.abi_version = 99
+    assert lib.pbf_create(C.byref(p), -1, C.byref(h)) == B.PBF_ERR_INVALID
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = B.default_params()
+    p.capacity = 16
+    with pytest.raises(B.PbfError) as e:
+        B.PbfContext(p)
+    assert e.value.code in (B.PBF_ERR_NO_DEVICE, B.PBF_ERR_HIP)
+
+
+def test_product_package_never_touches_the_oracle():
+    """the oracle is test infrastructure: nothing under fluidsimulation_amd/ may import or link it"""
+    for f in (ROOT / "fluidsimulation_amd").rglob("*"):
+        if f.suffix in {".py", ".hip", ".h", ".hpp", ".cpp", ".c"} or f.name == "Makefile":
+            text = f.read_text(errors="ignore")
+            assert "pyoracle" not in text and "pbf_oracle" not in text and "orc_" not in text, f

@@ -1,0 +1,262 @@
+"""CPU-only checks of the oracle itself: source-derived known answers, the
+reference's own compiled leaf sources (oracle/_ref, when present), NaiveSearch ==
+SpatialSearch, and the committed golden fixtures."""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from fluidsimulation_amd import aabb, scenes
+from fluidsimulation_amd import binding as B
+from oracle import pyoracle
+from oracle.pyoracle import f3
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+DT = 0.0005
+
+
+@pytest.fixture(scope="module")
+def lib(oracle_lib):
+    return oracle_lib
+
+
+# ------------------------------------------------------------------ known answers
+
+def test_poly6_kats(lib):
+    # Poly6_W(0,1) = 1.5666815; grad((.5,0,0), .5, 1).x = -2.64377499
+    assert lib.orc_poly6_w(0.0, 1.0) == np.float32(1.5666815)
+    out = (C.c_float * 3)()
+    lib.orc_poly6_w_gradient(f3((0.5, 0, 0)), 0.5, 1.0, out)
+    assert out[0] == np.float32(-2.64377499) and out[1] == 0 and out[2] == 0
+    # support is inclusive at d == h and empty beyond
+    assert lib.orc_poly6_w(1.0, 1.0) == 0.0
+    assert lib.orc_poly6_w(np.nextafter(np.float32(1), np.float32(2)), 1.0) == 0.0
+    assert lib.orc_poly6_w(-0.1, 1.0) == 0.0
+    # closed form in double with the float literal pi
+    pi = float(np.float32(3.1415926))
+    for d, h in [(0.3, 1.0), (0.02, 0.041528303), (0.9, 2.5)]:
+        d32, h32 = float(np.float32(d)), float(np.float32(h))
+        want = np.float32((315.0 / (64.0 * pi * h32 ** 9)) * (h32 * h32 - d32 * d32) ** 3)
+        got = lib.orc_poly6_w(d, h)
+        assert abs(got - want) <= abs(want) * 2e-7
+
+
+def test_spiky_kats(lib):
+    pi = float(np.float32(3.1415926))
+    assert lib.orc_spiky_w(0.0, 1.0) == np.float32(15.0 / pi)
+    out = (C.c_float * 3)()
+    lib.orc_spiky_w_gradient(f3((0.5, 0, 0)), 0.5, 1.0, out)
+    assert out[0] == np.float32(np.float32(-45.0 / pi * (0.25 / 0.5)) * np.float32(0.5))
+
+
+def test_setup_sim_params_constants(lib):
+    h, r, v = C.c_float(), C.c_float(), C.c_float()
+    lib.orc_setup_sim_params(C.byref(h), C.byref(r), C.byref(v))
+    # Simulation.cpp:324-326 -> h = 0.041528303, r = 0.012331058
+    assert np.float32(h.value) == np.float32(0.041528303)
+    # r is only pinned to one ulp: it goes through two powf calls and the reference's MSVC
+    # powf is unknown (glibc powf gives 0.012331059, numpy's float32 power 0.012331058)
+    ulp = np.spacing(np.float32(0.012331058))
+    assert abs(np.float32(r.value) - np.float32(0.012331058)) <= ulp
+    sh, sr, sv, _m, _rho = scenes.sim_params_constants()
+    assert sh == np.float32(h.value) and abs(sr - np.float32(r.value)) <= ulp and sv == np.float32(v.value)
+    # GenerateFluidCube: n = floor(0.5 / diameter) = 20 -> 8*20^3 = 64 000 particles
+    pos, _ = scenes.fluid_cube_reference()
+    assert pos.shape == (64000, 3)
+    assert pos[0].tolist() == [np.float32(-20) * np.float32(2 * sr), np.float32(0.75) + np.float32(-20) * np.float32(2 * sr), np.float32(-20) * np.float32(2 * sr)]
+
+
+def test_hash_and_flooring_kats(lib):
+    # NeighborSearch.cpp:255-266
+    assert lib.orc_hash_value(1, 2, 3) == (73856093 + 2 * 19349663 + 3 * 83492791) % 2 ** 32
+    assert lib.orc_hash_value(0, 0, 0) == 0
+    assert lib.orc_hash_value(-1, 0, 0) == (-73856093) % 2 ** 32
+    assert lib.orc_hash_value(-7, 12, -3) == (-7 * 73856093 + 12 * 19349663 - 3 * 83492791) % 2 ** 32
+    out = (C.c_int32 * 3)()
+    lib.orc_flooring(f3((-0.5, 0.0, 2.999)), 1.0, out)
+    assert list(out) == [-1, 0, 2]
+    lib.orc_flooring(f3((-0.0415, 0.0831, 1.0)), 0.041528303, out)
+    assert list(out) == [-1, 2, 24]
+
+
+def test_default_params_match_python_mirror(lib):
+    p = pyoracle.default_params()
+    q = B.default_params()
+    assert bytes(p) == bytes(q)
+
+
+# ------------------------------------------------------------------ the reference's own sources
+
+def test_leaf_arithmetic_equals_compiled_reference(lib):
+    """SPHKernel.h / CollisionDetection.cpp / vendored glm, compiled from /root/reference into
+    oracle/_ref, against the restatement on random inputs: bit-identical."""
+    ref = pyoracle.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference sources absent)")
+    rng = np.random.default_rng(2024)
+    out_a, out_b = (C.c_float * 3)(), (C.c_float * 3)()
+    for h in (1.0, 0.041528303, 2.5):
+        for _ in range(4000):
+            diff = (rng.uniform(-1, 1, 3) * h * 0.8).astype(np.float32)
+            d = np.float32(np.sqrt(np.float32(np.dot(diff, diff))))
+            if rng.random() < 0.1:
+                d = np.float32(h * rng.uniform(0.95, 1.1))
+            a, b = lib.orc_poly6_w(d, h), ref.ref_poly6_w(d, h)
+            assert np.float32(a).tobytes() == np.float32(b).tobytes()
+            assert np.float32(lib.orc_spiky_w(d, h)).tobytes() == np.float32(ref.ref_spiky_w(d, h)).tobytes()
+            lib.orc_poly6_w_gradient(f3(diff), d, h, out_a)
+            ref.ref_poly6_w_gradient(f3(diff), d, h, out_b)
+            assert bytes(out_a) == bytes(out_b)
+            if d > 0:
+                lib.orc_spiky_w_gradient(f3(diff), d, h, out_a)
+                ref.ref_spiky_w_gradient(f3(diff), d, h, out_b)
+                assert bytes(out_a) == bytes(out_b)
+    for _ in range(4000):
+        p = rng.uniform(-3, 3, 3).astype(np.float32)
+        n = rng.uniform(-1, 1, 3).astype(np.float32)
+        d = np.float32(rng.uniform(-2, 2))
+        assert lib.orc_point_plane(f3(p), f3(n), d) == ref.ref_point_plane(f3(p), f3(n), d)
+        mn = rng.uniform(-2, 0, 3).astype(np.float32)
+        mx = (mn + rng.uniform(0.5, 3, 3)).astype(np.float32)
+        assert lib.orc_point_aabb(f3(p), f3(mn), f3(mx)) == ref.ref_point_aabb(f3(p), f3(mn), f3(mx))
+    # on-the-boundary cases: <= is inclusive for planes, AABB is strict
+    assert ref.ref_point_plane(f3((0, 0, 0)), f3((0, 1, 0)), 0.0) == 1 == lib.orc_point_plane(f3((0, 0, 0)), f3((0, 1, 0)), 0.0)
+    assert ref.ref_point_aabb(f3((1, 0.5, 0.5)), f3((0, 0, 0)), f3((1, 1, 1))) == 0 == lib.orc_point_aabb(f3((1, 0.5, 0.5)), f3((0, 0, 0)), f3((1, 1, 1)))
+    # glm::pow(double, int) is std::pow (using std::pow, func_exponential.inl:88)
+    for x in rng.uniform(0, 2, 200):
+        assert ref.ref_glm_pow(float(x), 4) == float(x) ** 4.0 or abs(ref.ref_glm_pow(float(x), 4) - float(x) ** 4) <= 2e-16 * float(x) ** 4
+
+
+# ------------------------------------------------------------------ search
+
+def _jittered(nx, ny, nz, amp, seed):
+    p, pos, mass, cols = scenes.c1_lattice(nx, ny, nz)
+    rng = np.random.default_rng(seed)
+    pos = (pos + rng.uniform(-amp, amp, pos.shape)).astype(np.float32)
+    return p, pos, mass, cols
+
+
+def test_spatial_search_equals_naive_search():
+    """NeighborSearch.cpp:103-129 vs :131-236 -- the reference's own cross-check"""
+    p, pos, mass, _ = _jittered(6, 9, 5, 0.24, 1)
+    o = pyoracle.Oracle(p)
+    o.upload(pos, uniform_mass=mass)
+    o.spatial_search()
+    c1, n1 = o.neighbors(stride=64)
+    o.naive_search()
+    c2, n2 = o.neighbors(stride=64)
+    assert np.array_equal(c1, c2)
+    for i in range(pos.shape[0]):
+        assert set(n1[i, :c1[i]]) == set(n2[i, :c2[i]])
+    assert c1.max() > 10
+
+
+def test_neighbor_order_is_cell_loop_then_index():
+    """m_search_cache order: x outermost, z innermost, ascending index inside a bucket"""
+    p, pos, mass, _ = _jittered(4, 4, 4, 0.2, 5)
+    o = pyoracle.Oracle(p)
+    o.upload(pos, uniform_mass=mass)
+    o.spatial_search()
+    cells, _ = o.cells()
+    cnt, nb = o.neighbors(stride=64)
+    for i in range(pos.shape[0]):
+        js = nb[i, :cnt[i]]
+        rel = cells[js] - cells[i]
+        order = ((rel[:, 0] + 1) * 9 + (rel[:, 1] + 1) * 3 + (rel[:, 2] + 1)).astype(np.int64) * 10 ** 6 + js
+        assert np.all(np.diff(order) > 0)
+
+
+# ------------------------------------------------------------------ step semantics
+
+def test_predict_and_plane_response_by_hand():
+    p, pos, mass, cols = scenes.c1_lattice(1, 1, 1)
+    o = pyoracle.Oracle(p)
+    pos = np.array([[0.0, 0.001, -5.0]], np.float32)
+    vel = np.array([[1.0, -10.0, 0.0]], np.float32)
+    o.upload(pos, vel=vel, uniform_mass=mass)
+    o.set_colliders(cols)
+    o.predict_positions(DT)
+    _, v, pr, _ = o.download()
+    f = np.float32(DT)
+    m = np.float32(mass)
+    vy = np.float32(-10.0) + (f * (np.float32(1.0) / m)) * (m * np.float32(-9.8))
+    assert v[0, 1] == vy and pr[0, 1] == np.float32(0.001) + f * vy
+    o.collision_detection(DT)
+    _, v2, pr2, new2 = o.download()
+    # floor plane (0,1,0), d = 0: reflect, 0.99 restitution, re-predict from the old position
+    vr = vy - (np.float32(2.0) * vy) * np.float32(1.0)
+    assert v2[0, 1] == np.float32(0.99) * vr
+    assert pr2[0, 1] == np.float32(0.001) + f * v2[0, 1]
+    assert np.array_equal(pr2, new2)
+
+
+def test_aabb_response_picks_largest_distance_face():
+    p, _, mass, _ = scenes.c1_lattice(1, 1, 1)
+    o = pyoracle.Oracle(p)
+    pos = np.array([[0.2, 0.5, 0.5]], np.float32)
+    vel = np.array([[3.0, 0.0, 0.0]], np.float32)
+    o.upload(pos, vel=vel, uniform_mass=mass)
+    o.set_gravity(0, 0, 0)
+    o.set_colliders([aabb((0, 0, 0), (1, 1, 1))])
+    o.predict_positions(DT)
+    o.collision_detection(DT)
+    _, v, _, _ = o.download()
+    # diff2max.x = 0.8 is the largest of the six distances -> normal (1,0,0) (Particle.cpp:289-303)
+    assert v[0].tolist() == [np.float32(0.99) * np.float32(-3.0), 0.0, 0.0]
+
+
+def test_first_frame_rest_density_and_step_contract():
+    p, pos, mass, cols = scenes.c1_lattice(6, 6, 6, iterations=2)
+    o = pyoracle.Oracle(p)
+    o.upload(pos, uniform_mass=mass)
+    o.set_colliders(cols)
+    assert o.rest_density() == np.float32(0.8)  # Simulation.cpp:18
+    o.step(DT)
+    rho0 = o.rest_density()
+    assert 0.3 < rho0 < 0.8
+    o.step(DT)
+    assert o.rest_density() == rho0  # first frame only
+    pos1, vel1, pred1, new1 = o.download()
+    assert np.array_equal(pred1, new1) and np.array_equal(pos1, new1)
+    # interior density of the spacing-0.5 lattice, h = 1: m * sum W  ~ 0.808 (0.1 * 8.08)
+    o2 = pyoracle.Oracle(p)
+    o2.upload(pos, uniform_mass=mass)
+    o2.spatial_search()
+    o2.compute_rest_density()
+    dens, _, _ = o2.scalars()
+    centre = np.argmin(np.abs(pos - pos.mean(0)).sum(1))
+    assert dens[centre] == pytest.approx(0.8077, abs=2e-3)
+
+
+def test_oracle_threads_do_not_change_results():
+    p, pos, mass, cols = scenes.c1_lattice(6, 10, 6, iterations=2)
+    outs = []
+    for t in (1, 8):
+        o = pyoracle.Oracle(p, threads=t)
+        o.upload(pos, uniform_mass=mass)
+        o.set_colliders(cols)
+        for _ in range(3):
+            o.step(DT)
+        outs.append(o.download())
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ golden fixtures
+
+@pytest.mark.parametrize("name", sorted(p.stem for p in GOLDEN.glob("*.npz")))
+def test_oracle_reproduces_golden(name):
+    """tests/golden/*.npz were written by tests/golden/make_golden.py from this oracle; they pin
+    it against silent drift (and travel to the GPU box, where /root/reference does not exist)."""
+    from tests.golden.make_golden import build_case
+    z = np.load(GOLDEN / f"{name}.npz")
+    meta = json.loads(str(z["meta"]))
+    o, steps = build_case(meta, z["vel0"] if "vel0" in z else None,
+                          z["mass0"] if "mass0" in z else None)
+    for _ in range(steps):
+        o.step(DT)
+    pos, vel, _, _ = o.download()
+    assert np.array_equal(pos, z["pos"]) and np.array_equal(vel, z["vel"])
+    assert np.float32(o.rest_density()) == z["rest_density"]

@@ -19,15 +19,14 @@ struct KernConsts {
     double w_coef;      // 315 / (64 pi h^9)
     double spiky_coef;  // -45 / (pi h^6)
     double scorr_k;     // -scorr_k
+    double dt_pow;      // (double)dt multiplied scorr_dt_power times
+    double inv_w_dq;    // 1.0 / (double)w_dq
     float h;            // effective radius
     float hh;           // h * h in fp32 (square_h, NeighborSearch.cpp:139)
     float g_coef;       // (float)(-945 / (32 pi h^9))
     float w_zero;       // Poly6_W(0, h)
     float w_dq;         // Poly6_W(scorr_dq * h, h)
     float epsilon;
-    float dt;
-    int32_t scorr_dt_power;
-    int32_t grad_kernel;
 };
 
 struct GridConsts {
@@ -88,12 +87,13 @@ __device__ __forceinline__ float poly6_strict(const KernConsts& k, float distanc
     return 0.0f;
 }
 
-// ---- STRICT: SPHKernel::Poly6_W_Gradient / Spiky_W_Gradient scalar factor
+// ---- SPHKernel::Poly6_W_Gradient / Spiky_W_Gradient scalar factor
 // (SPHKernel.h:32-54, 78-97); the caller multiplies by diff
+template <int GRAD>
 __device__ __forceinline__ float grad_scalar_strict(const KernConsts& k, float distance) {
     if (distance >= 0 && distance <= k.h) {
         const double d = (double)distance;
-        if (k.grad_kernel == PBF_GRAD_SPIKY) {
+        if (GRAD == PBF_GRAD_SPIKY) {
             double q = k.hd - d;
             double q2 = q * q;
             double scalar = k.spiky_coef * (q2 / distance);
@@ -119,13 +119,47 @@ __device__ __forceinline__ double pow4_cr(double x) {
     return p + (pe + t);
 }
 
-// ---- STRICT artificial pressure (Simulation.cpp:698-702), returns (float)scorr
+// ---- artificial pressure (Simulation.cpp:698-702), returns (float)scorr.
+// x = W / W(dq) is a float division in the reference; here it is the product with the
+// double reciprocal rounded to float, which is the correctly rounded float quotient:
+// the product is within 2^-52 (relative) of the exact quotient, and the quotient of two
+// 24-bit floats lies at least 2^-49 away from any float rounding boundary.  (For subnormal
+// quotients ties can differ, but then x^4 underflows to 0 in the final float anyway.)
 __device__ __forceinline__ float scorr_strict(const KernConsts& k, float w) {
-    double x = (double)(w / k.w_dq);
-    x = pow4_cr(x);
+    float xf = (float)((double)w * k.inv_w_dq);
+    double x = pow4_cr((double)xf);
     double s = k.scorr_k * x;
-    for (int t = 0; t < k.scorr_dt_power; ++t) s = s * (double)k.dt;
+    s = s * k.dt_pow;
     return (float)s;
+}
+
+// Visit the neighbour row of particle i in order, with BATCH row entries and BATCH position
+// gathers in flight and the next batch of row entries prefetched behind them.  f(j, xj) is
+// called in row order (the summation order of the reference, Simulation.cpp:628,660,692).
+template <int BATCH, typename F>
+__device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t cnt,
+                                                  const uint32_t* __restrict__ nbr, uint32_t cap,
+                                                  const float4* __restrict__ x, F&& f) {
+    uint32_t jn[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) jn[u] = (uint32_t)u < cnt ? nbr[(size_t)u * cap + i] : i;
+    for (uint32_t k0 = 0; k0 < cnt; k0 += BATCH) {
+        uint32_t j[BATCH];
+        float4 xj[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            j[u] = jn[u];
+            xj[u] = x[j[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const uint32_t k = k0 + BATCH + u;
+            jn[u] = k < cnt ? nbr[(size_t)k * cap + i] : i;
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u)
+            if (k0 + u < cnt) f(j[u], xj[u]);
+    }
 }
 
 }  // namespace pbf

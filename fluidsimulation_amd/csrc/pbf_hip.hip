@@ -32,6 +32,7 @@ using namespace pbf;
 namespace {
 
 constexpr int BLOCK = 256;
+constexpr int SWEEP_BATCH = 4;                    // neighbour-row entries / gathers in flight
 constexpr int SCAN_ITEMS = 8;                     // items per thread in the scan tiles
 constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;     // 2048 cells per workgroup
 constexpr uint32_t MAX_SCAN_BLOCKS = 8192;        // second level handled by one workgroup
@@ -463,18 +464,15 @@ __global__ __launch_bounds__(BLOCK) void k_rest_density_terms(
     const float4* __restrict__ pos, const uint32_t* __restrict__ id,
     const uint32_t* __restrict__ nbr, const uint32_t* __restrict__ nbr_count, uint32_t n,
     uint32_t cap, KernConsts kc, float* __restrict__ dens_by_id) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
-    float4 pi = pos[i];
+    const float4 pi = pos[i];
     float dens = pi.w * kc.w_zero;
-    uint32_t cnt = nbr_count[i];
-    for (uint32_t k = 0; k < cnt; ++k) {
-        uint32_t j = nbr[(size_t)k * cap + i];
-        float4 pj = pos[j];
+    for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, pos, [&](uint32_t, const float4& pj) {
         float ex = pj.x - pi.x, ey = pj.y - pi.y, ez = pj.z - pi.z;
         float distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
         dens += pj.w * poly6_strict(kc, distance);
-    }
+    });
     dens_by_id[id[i]] = dens;
 }
 
@@ -492,7 +490,7 @@ __global__ void k_rest_density_mean(const float* __restrict__ dens_by_id, uint32
 // share one pass over the neighbour row: rho_i and sum_j |gradW/rho0|^2 are independent.
 // lambda is written into prd[i].w (no reader uses .w during this kernel).
 
-template <bool UNIFORM_MASS>
+template <bool UNIFORM_MASS, int GRAD>
 __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __restrict__ pos,
                                                   const uint32_t* __restrict__ nbr,
                                                   const uint32_t* __restrict__ nbr_count,
@@ -508,20 +506,17 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __r
     const float4 xi = prd[i];
     float dens = (UNIFORM_MASS ? uniform_mass : pos[i].w) * kc.w_zero;
     float grad_sum = 0.f;  // self term: |(1/rho0) gradW(0)|^2 == 0 (Simulation.cpp:657-658)
-    const uint32_t cnt = nbr_count[i];
-    for (uint32_t k = 0; k < cnt; ++k) {
-        uint32_t j = nbr[(size_t)k * cap + i];
-        float4 xj = prd[j];
+    for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, prd, [&](uint32_t j, const float4& xj) {
         float mj = UNIFORM_MASS ? uniform_mass : pos[j].w;
         float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
         float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
         float w = poly6_strict(kc, distance);
-        float gs = grad_scalar_strict(kc, distance);
+        float gs = grad_scalar_strict<GRAD>(kc, distance);
         dens += mj * w;
         // gradientC_j = (1/rho0) * (gs * diff); sum += dot(gC, gC)
         float gx = inv_rho0 * (gs * dx), gy = inv_rho0 * (gs * dy), gz = inv_rho0 * (gs * dz);
         grad_sum += dot3(gx, gy, gz, gx, gy, gz);
-    }
+    });
     float C = dens / rho0 - 1.f;
     float lam = -C;
     lam /= grad_sum + kc.epsilon;
@@ -534,6 +529,7 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __r
 // Jacobi hand-over copy directly (UpdatePredictPosition, :714-721), plus the build-side
 // container clamp.  Accumulates onto new_i in neighbour-row order like the reference.
 
+template <int GRAD>
 __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
                                                  float4* __restrict__ prd_out,
                                                  const uint32_t* __restrict__ nbr,
@@ -546,20 +542,17 @@ __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
     const float inv_rho0 = 1.f / *rho0_ptr;
     const float4 xi = prd[i];
     float nx = xi.x, ny = xi.y, nz = xi.z;
-    const uint32_t cnt = nbr_count[i];
-    for (uint32_t k = 0; k < cnt; ++k) {
-        uint32_t j = nbr[(size_t)k * cap + i];
-        float4 xj = prd[j];
+    for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, prd, [&](uint32_t, const float4& xj) {
         float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
         float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
         float sc = scorr_strict(kc, poly6_strict(kc, distance));
-        float gs = grad_scalar_strict(kc, distance);
+        float gs = grad_scalar_strict<GRAD>(kc, distance);
         // result = (1/rho0) * (lambda_i + lambda_j + (float)scorr) * gradW
         float s = inv_rho0 * (xi.w + xj.w + sc);
         nx += s * (gs * dx);
         ny += s * (gs * dy);
         nz += s * (gs * dz);
-    }
+    });
     if (container) {
         nx = nx < cmin.x ? cmin.x : nx;
         nx = nx > cmax.x ? cmax.x : nx;
@@ -588,6 +581,7 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(float4* __restrict__ pos,
 // a20 (no reference counterpart): vorticity confinement + XSPH viscosity after Macklin &
 // Mueller 2013 eqs. 15-17 on the frozen neighbour rows and the updated positions.
 
+template <int GRAD>
 __global__ __launch_bounds__(BLOCK) void k_vorticity(const float4* __restrict__ pos,
                                                      const float4* __restrict__ vel,
                                                      const uint32_t* __restrict__ nbr,
@@ -599,23 +593,21 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(const float4* __restrict__ 
     const float4 pi = pos[i];
     const float4 vi = vel[i];
     float wx = 0.f, wy = 0.f, wz = 0.f;
-    const uint32_t cnt = nbr_count[i];
-    for (uint32_t k = 0; k < cnt; ++k) {
-        uint32_t j = nbr[(size_t)k * cap + i];
-        float4 pj = pos[j];
+    for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, pos, [&](uint32_t j, const float4& pj) {
         float4 vj = vel[j];
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
-        float gs = grad_scalar_strict(kc, distance);
+        float gs = grad_scalar_strict<GRAD>(kc, distance);
         float gx = gs * dx, gy = gs * dy, gz = gs * dz;
         float ux = vj.x - vi.x, uy = vj.y - vi.y, uz = vj.z - vi.z;
         wx += uy * gz - gy * uz;
         wy += uz * gx - gz * ux;
         wz += ux * gy - gx * uy;
-    }
+    });
     omega[i] = make_float4(wx, wy, wz, sqrtf(dot3(wx, wy, wz, wx, wy, wz)));
 }
 
+template <int GRAD>
 __global__ __launch_bounds__(BLOCK) void k_vorticity_apply(
     const float4* __restrict__ pos, const float4* __restrict__ vel,
     const float4* __restrict__ omega, const uint32_t* __restrict__ nbr,
@@ -626,18 +618,15 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity_apply(
     const float inv_rho0 = 1.f / *rho0_ptr;
     const float4 pi = pos[i];
     float ex = 0.f, ey = 0.f, ez = 0.f;
-    const uint32_t cnt = nbr_count[i];
-    for (uint32_t k = 0; k < cnt; ++k) {
-        uint32_t j = nbr[(size_t)k * cap + i];
-        float4 pj = pos[j];
+    for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, pos, [&](uint32_t j, const float4& pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
-        float gs = grad_scalar_strict(kc, distance);
+        float gs = grad_scalar_strict<GRAD>(kc, distance);
         float s = (pj.w * inv_rho0) * omega[j].w;
         ex += s * (gs * dx);
         ey += s * (gs * dy);
         ez += s * (gs * dz);
-    }
+    });
     float len = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
     float4 v = vel[i];
     if (len > 0.f) {
@@ -667,10 +656,7 @@ __global__ __launch_bounds__(BLOCK) void k_xsph(const float4* __restrict__ pos,
     const float4 pi = pos[i];
     const float4 vi = vel[i];
     float ax = 0.f, ay = 0.f, az = 0.f;
-    const uint32_t cnt = nbr_count[i];
-    for (uint32_t k = 0; k < cnt; ++k) {
-        uint32_t j = nbr[(size_t)k * cap + i];
-        float4 pj = pos[j];
+    for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, pos, [&](uint32_t j, const float4& pj) {
         float4 vj = vel[j];
         float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
         float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
@@ -678,7 +664,7 @@ __global__ __launch_bounds__(BLOCK) void k_xsph(const float4* __restrict__ pos,
         ax += s * (vj.x - vi.x);
         ay += s * (vj.y - vi.y);
         az += s * (vj.z - vi.z);
-    }
+    });
     vel_out[i] = make_float4(vi.x + c * ax, vi.y + c * ay, vi.z + c * az, 0.f);
 }
 
@@ -880,10 +866,10 @@ KernConsts make_kern(const pbf_params& P, float dt) {
         double d = (double)dq, q = k.h2 - d * d;
         k.w_dq = (dq >= 0 && dq <= k.h) ? (float)(k.w_coef * (q * q * q)) : 0.f;
     }
+    k.inv_w_dq = k.w_dq != 0.f ? 1.0 / (double)k.w_dq : 0.0;
+    k.dt_pow = 1.0;
+    for (int t = 0; t < P.scorr_dt_power; ++t) k.dt_pow = k.dt_pow * (double)dt;
     k.epsilon = P.epsilon;
-    k.dt = dt;
-    k.scorr_dt_power = P.scorr_dt_power;
-    k.grad_kernel = P.gradient_kernel;
     return k;
 }
 
@@ -1315,24 +1301,31 @@ int pbf_solve(pbf_ctx* c, int32_t iterations, float dt) {
     float3_ cmin = {c->P.container_min[0], c->P.container_min[1], c->P.container_min[2]};
     float3_ cmax = {c->P.container_max[0], c->P.container_max[1], c->P.container_max[2]};
     const uint32_t nb = nblocks(c->n);
+    const bool spiky = c->P.gradient_kernel == PBF_GRAD_SPIKY;
     for (int32_t it = 0; it < iterations; ++it) {
         float4* x = c->prd[c->prd_cur];
         float4* y = c->prd[(c->prd_cur + 1) % 3];
         {
             PhaseScope ps(c, PH_LAMBDA);
-            if (c->uniform)
-                k_lambda<true><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count,
-                                                            c->n, c->cap, kc, c->rho0,
-                                                            c->uniform_mass, c->dens, c->C);
-            else
-                k_lambda<false><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count,
-                                                             c->n, c->cap, kc, c->rho0,
-                                                             c->uniform_mass, c->dens, c->C);
+#define LAUNCH_LAMBDA(U, G)                                                                   \
+    k_lambda<U, G><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count, c->n, \
+                                                c->cap, kc, c->rho0, c->uniform_mass, c->dens, c->C)
+            if (c->uniform && !spiky) LAUNCH_LAMBDA(true, PBF_GRAD_POLY6);
+            else if (c->uniform) LAUNCH_LAMBDA(true, PBF_GRAD_SPIKY);
+            else if (!spiky) LAUNCH_LAMBDA(false, PBF_GRAD_POLY6);
+            else LAUNCH_LAMBDA(false, PBF_GRAD_SPIKY);
+#undef LAUNCH_LAMBDA
         }
         {
             PhaseScope ps(c, PH_DELTA);
-            k_delta<<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n, c->cap, kc,
-                                                 c->rho0, c->P.container_enabled, cmin, cmax);
+            if (!spiky)
+                k_delta<PBF_GRAD_POLY6><<<nb, BLOCK, 0, c->stream>>>(
+                    x, y, c->nbr, c->nbr_count, c->n, c->cap, kc, c->rho0, c->P.container_enabled,
+                    cmin, cmax);
+            else
+                k_delta<PBF_GRAD_SPIKY><<<nb, BLOCK, 0, c->stream>>>(
+                    x, y, c->nbr, c->nbr_count, c->n, c->cap, kc, c->rho0, c->P.container_enabled,
+                    cmin, cmax);
         }
         c->prd_cur = (c->prd_cur + 1) % 3;
     }
@@ -1358,11 +1351,19 @@ int pbf_finalize(pbf_ctx* c, float dt) {
         float4* va = c->vel[c->cur];
         float4* vb = c->vel[1 - c->cur];
         if (c->P.vorticity_eps != 0.f) {
-            k_vorticity<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], va, c->nbr, c->nbr_count, c->n,
-                                                     c->cap, kc, c->omega);
-            k_vorticity_apply<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], va, c->omega, c->nbr,
-                                                           c->nbr_count, c->n, c->cap, kc, c->rho0,
-                                                           dt, c->P.vorticity_eps, vb);
+            if (c->P.gradient_kernel == PBF_GRAD_SPIKY) {
+                k_vorticity<PBF_GRAD_SPIKY><<<nb, BLOCK, 0, c->stream>>>(
+                    c->pos[c->cur], va, c->nbr, c->nbr_count, c->n, c->cap, kc, c->omega);
+                k_vorticity_apply<PBF_GRAD_SPIKY><<<nb, BLOCK, 0, c->stream>>>(
+                    c->pos[c->cur], va, c->omega, c->nbr, c->nbr_count, c->n, c->cap, kc, c->rho0,
+                    dt, c->P.vorticity_eps, vb);
+            } else {
+                k_vorticity<PBF_GRAD_POLY6><<<nb, BLOCK, 0, c->stream>>>(
+                    c->pos[c->cur], va, c->nbr, c->nbr_count, c->n, c->cap, kc, c->omega);
+                k_vorticity_apply<PBF_GRAD_POLY6><<<nb, BLOCK, 0, c->stream>>>(
+                    c->pos[c->cur], va, c->omega, c->nbr, c->nbr_count, c->n, c->cap, kc, c->rho0,
+                    dt, c->P.vorticity_eps, vb);
+            }
             float4* t = va; va = vb; vb = t;
         }
         if (c->P.xsph_c != 0.f) {

@@ -652,7 +652,11 @@ int orc_compute_correction(orc_ctx* c, float dt) {
     const float inv_rho0 = 1.f / c->rest_density;
     const float w_dq = k_poly6(&k, c->P.scorr_dq * c->P.effective_radius); /* :700 */
     const double scorr_k = -c->P.scorr_k;
-    const int dtp = c->P.scorr_dt_power;
+    /* scorr * x * dt (Simulation.cpp:702); for scorr_dt_power != 1 (build-side) dt is
+     * replaced by (double)dt multiplied that many times */
+    double dt_pow = 1.0;
+    for (int t = 0; t < c->P.scorr_dt_power; ++t) dt_pow = dt_pow * (double)dt;
+    if (c->P.scorr_dt_power == 1) dt_pow = (double)dt;
 #pragma omp parallel for schedule(dynamic, 64) num_threads(c->threads)
     for (int i = 0; i < n; ++i) {
         const float* pi = c->pred + 3 * i;
@@ -666,8 +670,7 @@ int orc_compute_correction(orc_ctx* c, float dt) {
             double scorr = scorr_k;
             double x = k_poly6(&k, distance) / w_dq; /* float / float, then promoted */
             x = pow(x, 4);
-            scorr = scorr * x;
-            for (int t = 0; t < dtp; ++t) scorr = scorr * dt;
+            scorr = scorr * x * dt_pow;
             float g[3];
             k_grad(&k, diff, distance, g);
             float s = inv_rho0 * (c->lambda[i] + c->lambda[j] + (float)scorr);

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output directories (kernel stats and --pmc passes) into a small text/JSON
+report for profiles/.  Usage: summarize_prof.py <pmc_dir> [<kernel_stats.csv>] > report.md"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0]
+
+
+def main():
+    pmc_dir = sys.argv[1]
+    agg = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(lambda: defaultdict(int))
+    for f in glob.glob(f"{pmc_dir}/*/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            c = r["Counter_Name"]
+            agg[k][c] += float(r["Counter_Value"])
+            calls[k][c] += 1
+    out = {}
+    for k in agg:
+        out[k] = {c: agg[k][c] / max(1, calls[k][c]) for c in agg[k]}   # per-launch averages
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

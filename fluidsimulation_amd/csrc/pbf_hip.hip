@@ -412,26 +412,36 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ 
     // the three z-cells of one (dx,dy) are consecutive keys unless the z index wraps
     const bool zrun = wz >= 1u && wz + 1u < (uint32_t)G.gz;
     uint32_t cnt = 0;
-    // candidate range [a,b): batches of 4 loads in flight, tested in order
+    uint32_t* out = nbr + i;  // advances one row (cap entries) per accepted neighbour
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 pix = {xi.x, xi.x}, piy = {xi.y, xi.y}, piz = {xi.z, xi.z};
+    auto accept = [&](uint32_t ju) {
+        if (cnt < K) {
+            *out = ju;
+            out += cap;
+        }
+        ++cnt;
+    };
+    // candidate range [a,b): batches of 4 loads in flight, tested two at a time with packed
+    // fp32 math (each lane of a packed op rounds like the scalar op: still glm's dot order),
+    // accepted in order
     auto sweep = [&](uint32_t a, uint32_t b) {
         for (uint32_t j = a; j < b; j += 4) {
             const uint32_t last = b - 1;
             const uint32_t j1 = j + 1 < b ? j + 1 : last, j2 = j + 2 < b ? j + 2 : last,
                            j3 = j + 3 < b ? j + 3 : last;
             const float4 c0 = prd[j], c1 = prd[j1], c2 = prd[j2], c3 = prd[j3];
-            const float4 cs4[4] = {c0, c1, c2, c3};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t ju = j + u;
-                if (ju >= b || ju == i) continue;
-                // glm::distance2(pi, pj) = dot(pj - pi, pj - pi)
-                const float ex = cs4[u].x - xi.x, ey = cs4[u].y - xi.y, ez = cs4[u].z - xi.z;
-                const float d2 = dot3(ex, ey, ez, ex, ey, ez);
-                if (d2 <= square_h) {
-                    if (cnt < K) nbr[(size_t)cnt * cap + i] = ju;
-                    ++cnt;
-                }
-            }
+            // glm::distance2(pi, pj) = dot(pj - pi, pj - pi)
+            f2 ex = (f2){c0.x, c1.x} - pix, ey = (f2){c0.y, c1.y} - piy, ez = (f2){c0.z, c1.z} - piz;
+            const f2 da = (ex * ex + ey * ey) + ez * ez;
+            ex = (f2){c2.x, c3.x} - pix;
+            ey = (f2){c2.y, c3.y} - piy;
+            ez = (f2){c2.z, c3.z} - piz;
+            const f2 db = (ex * ex + ey * ey) + ez * ez;
+            if (da.x <= square_h && j != i) accept(j);
+            if (da.y <= square_h && j + 1 < b && j + 1 != i) accept(j + 1);
+            if (db.x <= square_h && j + 2 < b && j + 2 != i) accept(j + 2);
+            if (db.y <= square_h && j + 3 < b && j + 3 != i) accept(j + 3);
         }
     };
     for (int dx = -1; dx <= 1; ++dx) {

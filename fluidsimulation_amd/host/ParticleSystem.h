@@ -1,0 +1,39 @@
+// ParticleSystem.h -- owner of the fluid ParticleSet and of its device twin.
+// Mirrors the call surface of the reference's ParticleSystem (reference
+// ParticleSystem.h:11-46) without its GL VAO/VBO and CUDA-GL interop members.
+#pragma once
+#include <memory>
+#include <string>
+#include "Particle.h"
+#include "pbf.h"
+
+class ParticleSystem {
+public:
+    ParticleSystem() = default;
+    ~ParticleSystem();
+    ParticleSystem(const ParticleSystem&) = delete;
+    ParticleSystem& operator=(const ParticleSystem&) = delete;
+
+    // ParticleSystem.cpp:99-103
+    ParticleSet* AllocateParticles(size_t n, float particle_mass);
+    ParticleSet* getParticles() { return m_particles.get(); }
+    void setParticleRadius(float r) { m_particle_radius = r; }
+    float getParticleRadius() const { return m_particle_radius; }
+
+    // replaces Initialize()/InitializeCUDA() (ParticleSystem.cpp:30-36,116-348): creates the
+    // device arrays for `params` and uploads the host vectors.  false on failure (see error()).
+    bool InitializeDevice(const pbf_params& params, int device = -1);
+    // replaces Update()/UpdateGLBUfferData (ParticleSystem.cpp:38-49,372-406): instead of
+    // re-uploading positions to a GL buffer, refreshes the HOST vectors from the device.
+    bool Update();
+    void Release();  // ParticleSystem.cpp:59-97
+
+    pbf_ctx* context() { return m_ctx; }
+    const std::string& error() const { return m_error; }
+
+private:
+    std::unique_ptr<ParticleSet> m_particles;
+    float m_particle_radius = 0.f;
+    pbf_ctx* m_ctx = nullptr;
+    std::string m_error;
+};

@@ -1,0 +1,47 @@
+"""GPU: the C++ host facade (Simulation / ParticleSystem / NeighborSearch / ConstraintSolver,
+fluidsimulation_amd/host) driven by the headless pbf_run binary, against the CPU oracle."""
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from fluidsimulation_amd import scenes
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+RUN = ROOT / "fluidsimulation_amd" / "host" / "pbf_run"
+
+
+def read_dump(path):
+    b = Path(path).read_bytes()
+    n = struct.unpack_from("<Q", b, 0)[0]
+    pos = np.frombuffer(b, np.float32, n * 3, 8).reshape(n, 3)
+    vel = np.frombuffer(b, np.float32, n * 3, 8 + n * 12).reshape(n, 3)
+    k = struct.unpack_from("<Q", b, 8 + n * 24)[0]
+    nb0 = np.frombuffer(b, np.uint64, k, 16 + n * 24)
+    return pos, vel, nb0
+
+
+@pytest.mark.parametrize("dims,steps,iters", [((6, 12, 6), 4, 2), ((10, 100, 10), 3, 2)])
+def test_headless_driver_matches_oracle(tmp_path, dims, steps, iters):
+    assert RUN.exists(), "pbf_run not built: run __graft_entry__.build()"
+    dump = tmp_path / "state.bin"
+    r = subprocess.run([str(RUN), "--dims", *map(str, dims), "--steps", str(steps), "--iters", str(iters),
+                        "--dump", str(dump)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    pos, vel, nb0 = read_dump(dump)
+    p, ipos, mass, cols = scenes.c1_lattice(*dims, iterations=iters)
+    o = pyoracle.Oracle(p)
+    o.upload(ipos, uniform_mass=mass)
+    o.set_colliders(cols)
+    for _ in range(steps):
+        o.step(0.0005)
+    op, ov, _, _ = o.download()
+    assert np.array_equal(pos, op) and np.array_equal(vel, ov)
+    oc, on = o.neighbors()
+    assert nb0.tolist() == on[0, :oc[0]].tolist()   # FetchNeighbors(0) in m_search_cache order
+    assert f"rest_density {o.rest_density():.9g}" in r.stdout

@@ -151,7 +151,9 @@ SYMBOLS = [
     "pbf_step", "pbf_sync", "pbf_download", "pbf_get_scalars", "pbf_get_cells",
     "pbf_get_neighbors", "pbf_get_stats", "pbf_get_rest_density", "pbf_num_particles",
     "pbf_profile_enable", "pbf_profile_reset", "pbf_profile_read", "pbf_num_phases",
-    "pbf_phase_name",
+    "pbf_phase_name", "pbf_solve_lambda", "pbf_solve_delta", "pbf_finalize_stage", "pbf_set_stream",
+    "pbf_slab_set_bounds", "pbf_slab_partition", "pbf_slab_append", "pbf_slab_pack_ghosts",
+    "pbf_slab_pack_halo", "pbf_slab_unpack_halo", "pbf_slab_export",
 ]
 
 _lib = None
@@ -203,6 +205,17 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_num_phases.restype = C.c_uint32
     lib.pbf_phase_name.argtypes = [C.c_uint32]
     lib.pbf_phase_name.restype = C.c_char_p
+    lib.pbf_solve_lambda.argtypes = [vp, C.c_float]
+    lib.pbf_solve_delta.argtypes = [vp, C.c_float]
+    lib.pbf_finalize_stage.argtypes = [vp, C.c_int32, C.c_float]
+    lib.pbf_set_stream.argtypes = [vp, vp]
+    lib.pbf_slab_set_bounds.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.pbf_slab_partition.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32 * 3)]
+    lib.pbf_slab_append.argtypes = [vp, vp, C.c_uint32, C.c_int32]
+    lib.pbf_slab_pack_ghosts.argtypes = [vp, C.c_int32, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.pbf_slab_pack_halo.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    lib.pbf_slab_unpack_halo.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_uint32]
+    lib.pbf_slab_export.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     if path is None:
         _lib = lib
     return lib
@@ -332,6 +345,49 @@ class PbfContext:
         v = C.c_float()
         self._ck(self.lib.pbf_get_rest_density(self._h, C.byref(v)))
         return float(v.value)
+
+    # -- split iteration / staged finalize / slab decomposition (device pointers are ints)
+    def solve_lambda(self, dt):
+        self._ck(self.lib.pbf_solve_lambda(self._h, C.c_float(dt)))
+
+    def solve_delta(self, dt):
+        self._ck(self.lib.pbf_solve_delta(self._h, C.c_float(dt)))
+
+    def finalize_stage(self, stage, dt):
+        self._ck(self.lib.pbf_finalize_stage(self._h, stage, C.c_float(dt)))
+
+    def set_stream(self, stream_handle: int):
+        self._ck(self.lib.pbf_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def slab_set_bounds(self, x_lo: int, x_hi: int):
+        self._ck(self.lib.pbf_slab_set_bounds(self._h, x_lo, x_hi))
+
+    def slab_partition(self, d_left: int, d_right: int, max_records: int):
+        counts = (C.c_uint32 * 3)()
+        self._ck(self.lib.pbf_slab_partition(self._h, C.c_void_p(d_left), C.c_void_p(d_right),
+                                             max_records, C.byref(counts)))
+        self.n = int(counts[0])
+        return int(counts[0]), int(counts[1]), int(counts[2])
+
+    def slab_append(self, d_records: int, count: int, ghost_side: int = -1):
+        self._ck(self.lib.pbf_slab_append(self._h, C.c_void_p(d_records or None), count, ghost_side))
+        self.n += count
+
+    def slab_pack_ghosts(self, side: int, d_out: int, max_records: int) -> int:
+        k = C.c_uint32()
+        self._ck(self.lib.pbf_slab_pack_ghosts(self._h, side, C.c_void_p(d_out), max_records, C.byref(k)))
+        return int(k.value)
+
+    def slab_pack_halo(self, side: int, what: int, d_out: int):
+        self._ck(self.lib.pbf_slab_pack_halo(self._h, side, what, C.c_void_p(d_out or None)))
+
+    def slab_unpack_halo(self, side: int, what: int, d_in: int, count: int):
+        self._ck(self.lib.pbf_slab_unpack_halo(self._h, side, what, C.c_void_p(d_in or None), count))
+
+    def slab_export(self, d_records: int, max_records: int) -> int:
+        k = C.c_uint32()
+        self._ck(self.lib.pbf_slab_export(self._h, C.c_void_p(d_records), max_records, C.byref(k)))
+        return int(k.value)
 
     # -- device-time profile
     def profile_enable(self, on=True):

@@ -15,6 +15,7 @@
 // phase is HBM/L2-bandwidth or latency bound.  Compiled with -ffp-contract=off.
 
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -87,6 +88,7 @@ __global__ void k_unpack3(const float4* __restrict__ a, const uint32_t* __restri
                           float* __restrict__ out3) {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (id[i] & 0x80000000u) return;  // slab ghost
     float4 v = a[i];
     size_t o = 3 * (size_t)id[i];
     out3[o] = v.x;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(BLOCK) void k_predict(const float4* __restrict__ po
                      floor_cell(qz, G.spacing));
         key[i] = k;
     }
-    histogram_add(cell_count, k, active);
+    if (cell_count) histogram_add(cell_count, k, active);
 }
 
 // re-key without predicting (pbf_build_grid called on its own)
@@ -375,16 +377,19 @@ __global__ __launch_bounds__(BLOCK) void k_reorder(
     const uint32_t* __restrict__ tmp_src, const uint32_t* __restrict__ tmp_id, uint32_t n,
     const float4* __restrict__ pos_in, const float4* __restrict__ vel_in,
     const float4* __restrict__ prd_in, float4* __restrict__ pos_out, float4* __restrict__ vel_out,
-    float4* __restrict__ prd_out, uint32_t* __restrict__ id_out) {
+    float4* __restrict__ prd_out, uint32_t* __restrict__ id_out, uint32_t* __restrict__ slot_of) {
     uint32_t s = blockIdx.x * BLOCK + threadIdx.x;
     if (s >= n) return;
     uint32_t src = tmp_src[s];
     uint32_t my = tmp_id[s];
     uint32_t k = key[src];
     uint32_t a = cell_start[k], b = cell_start[k + 1];
+    // rank inside the cell by original id (bit 31 marks slab ghosts and is not part of the id)
+    const uint32_t my_id = my & 0x7fffffffu;
     uint32_t rank = 0;
-    for (uint32_t t = a; t < b; ++t) rank += (tmp_id[t] < my) ? 1u : 0u;
+    for (uint32_t t = a; t < b; ++t) rank += ((tmp_id[t] & 0x7fffffffu) < my_id) ? 1u : 0u;
     uint32_t dst = a + rank;
+    if (slot_of) slot_of[src] = dst;
     pos_out[dst] = pos_in[src];
     vel_out[dst] = vel_in[src];
     prd_out[dst] = prd_in[src];
@@ -679,6 +684,127 @@ __global__ __launch_bounds__(BLOCK) void k_xsph(const float4* __restrict__ pos,
 }
 
 // ------------------------------------------------------------------------------------
+// slab decomposition (no reference counterpart).  A rank owns the cells whose
+// x index lies in [x_lo, x_hi).  Records are 12 floats: pos.xyz, mass, vel.xyz, id (bits),
+// prd.xyz, 0.  Ghost particles carry bit 31 of their id.  Compaction order is arbitrary
+// (device atomics): the counting sort re-establishes the canonical (cell, id) order.
+
+constexpr uint32_t GHOST_BIT = 0x80000000u;
+
+struct SlabCounters {
+    uint32_t stay, left, right, ghosts, exported;
+};
+
+__device__ __forceinline__ void write_record(float* rec, const float4& p, const float4& v,
+                                             uint32_t id, const float4& q) {
+    float4* r = reinterpret_cast<float4*>(rec);
+    r[0] = p;
+    r[1] = make_float4(v.x, v.y, v.z, __uint_as_float(id));
+    r[2] = make_float4(q.x, q.y, q.z, 0.f);
+}
+
+// after predict: drop ghosts, keep stayers (compacted into the spare buffers), pack leavers
+__global__ __launch_bounds__(BLOCK) void k_slab_partition(
+    const float4* __restrict__ pos, const float4* __restrict__ vel, const float4* __restrict__ prd,
+    const uint32_t* __restrict__ id, uint32_t n, float spacing, int32_t x_lo, int32_t x_hi,
+    float4* __restrict__ pos_o, float4* __restrict__ vel_o, float4* __restrict__ prd_o,
+    uint32_t* __restrict__ id_o, float* __restrict__ rec_left, float* __restrict__ rec_right,
+    uint32_t max_records, SlabCounters* __restrict__ cnt) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pid = id[i];
+    if (pid & GHOST_BIT) return;
+    const float4 q = prd[i];
+    const int32_t cx = floor_cell(q.x, spacing);
+    if (cx < x_lo) {
+        uint32_t s = atomicAdd(&cnt->left, 1u);
+        if (s < max_records) write_record(rec_left + 12 * (size_t)s, pos[i], vel[i], pid, q);
+    } else if (cx >= x_hi) {
+        uint32_t s = atomicAdd(&cnt->right, 1u);
+        if (s < max_records) write_record(rec_right + 12 * (size_t)s, pos[i], vel[i], pid, q);
+    } else {
+        uint32_t s = atomicAdd(&cnt->stay, 1u);
+        pos_o[s] = pos[i];
+        vel_o[s] = vel[i];
+        prd_o[s] = q;
+        id_o[s] = pid;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_slab_append(const float* __restrict__ rec, uint32_t count,
+                                                       uint32_t base, uint32_t ghost_flag,
+                                                       float4* __restrict__ pos,
+                                                       float4* __restrict__ vel,
+                                                       float4* __restrict__ prd,
+                                                       uint32_t* __restrict__ id) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const float4* r = reinterpret_cast<const float4*>(rec + 12 * (size_t)i);
+    float4 p = r[0], v = r[1], q = r[2];
+    uint32_t pid = (__float_as_uint(v.w) & ~GHOST_BIT) | ghost_flag;
+    pos[base + i] = p;
+    vel[base + i] = make_float4(v.x, v.y, v.z, 0.f);
+    prd[base + i] = make_float4(q.x, q.y, q.z, 0.f);
+    id[base + i] = pid;
+}
+
+// owned particles in the boundary cell plane `plane` -> ghost records + boundary list
+__global__ __launch_bounds__(BLOCK) void k_slab_pack_ghosts(
+    const float4* __restrict__ pos, const float4* __restrict__ vel, const float4* __restrict__ prd,
+    const uint32_t* __restrict__ id, uint32_t n, float spacing, int32_t plane,
+    float* __restrict__ rec, uint32_t max_records, uint32_t* __restrict__ blist,
+    uint32_t* __restrict__ counter) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pid = id[i];
+    if (pid & GHOST_BIT) return;
+    const float4 q = prd[i];
+    if (floor_cell(q.x, spacing) != plane) return;
+    uint32_t s = atomicAdd(counter, 1u);
+    if (s < max_records) {
+        write_record(rec + 12 * (size_t)s, pos[i], vel[i], pid, q);
+        blist[s] = i;
+    }
+}
+
+// halo refresh: boundary list (pre-sort indices) -> sorted slots -> float4 payload
+__global__ __launch_bounds__(BLOCK) void k_slab_pack_halo(const float4* __restrict__ src,
+                                                          const uint32_t* __restrict__ blist,
+                                                          const uint32_t* __restrict__ slot_of,
+                                                          uint32_t count, float4* __restrict__ out) {
+    uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= count) return;
+    out[e] = src[slot_of[blist[e]]];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_slab_unpack_halo(float4* __restrict__ dst,
+                                                            const uint32_t* __restrict__ slot_of,
+                                                            uint32_t ghost_base, uint32_t count,
+                                                            const float4* __restrict__ in,
+                                                            int keep_w) {
+    uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= count) return;
+    const uint32_t slot = slot_of[ghost_base + e];
+    float4 v = in[e];
+    if (keep_w) v.w = dst[slot].w;
+    dst[slot] = v;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_slab_export(const float4* __restrict__ pos,
+                                                       const float4* __restrict__ vel,
+                                                       const float4* __restrict__ prd,
+                                                       const uint32_t* __restrict__ id, uint32_t n,
+                                                       float* __restrict__ rec, uint32_t max_records,
+                                                       uint32_t* __restrict__ counter) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pid = id[i];
+    if (pid & GHOST_BIT) return;
+    uint32_t s = atomicAdd(counter, 1u);
+    if (s < max_records) write_record(rec + 12 * (size_t)s, pos[i], vel[i], pid, prd[i]);
+}
+
+// ------------------------------------------------------------------------------------
 // diagnostics
 
 __global__ __launch_bounds__(BLOCK) void k_cells_by_id(const float4* __restrict__ prd,
@@ -721,12 +847,14 @@ struct StatPartial {
 __global__ __launch_bounds__(BLOCK) void k_stats(const float4* __restrict__ pos,
                                                  const float4* __restrict__ vel,
                                                  const float* __restrict__ C,
-                                                 const uint32_t* __restrict__ nbr_count, uint32_t n,
+                                                 const uint32_t* __restrict__ nbr_count,
+                                                 const uint32_t* __restrict__ id, uint32_t n,
                                                  StatPartial* __restrict__ partials) {
     __shared__ StatPartial sh[BLOCK / 64];
     StatPartial a;
     memset(&a, 0, sizeof(a));
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        if (id[i] & 0x80000000u) continue;  // slab ghost
         float4 p = pos[i];
         if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {
             a.nonfinite++;
@@ -814,6 +942,15 @@ struct pbf_ctx {
     StatPartial* stat_partials = nullptr;
     ColliderSet colliders;
     bool first_frame = true;
+    // slab decomposition state
+    bool slab = false;
+    int32_t x_lo = INT32_MIN, x_hi = INT32_MAX;
+    uint32_t* slot_of = nullptr;          // pre-sort index -> sorted slot of the last sort
+    uint32_t* blist[2] = {nullptr, nullptr};  // boundary-plane particles (pre-sort indices)
+    uint32_t bcount[2] = {0, 0};
+    uint32_t ghost_base[2] = {0, 0}, ghost_count[2] = {0, 0};
+    SlabCounters* slab_cnt = nullptr;
+    bool owns_stream = true;
     bool uniform = false;      // every particle has uniform_mass (no per-neighbour mass gather)
     float uniform_mass = 0.f;
     bool keyed = false;  // histogram of the live prd already accumulated by k_predict
@@ -993,7 +1130,7 @@ int sort_and_neighbors(pbf_ctx* c) {
                                                            c->tmp_src, c->tmp_id);
             k_reorder<<<nblocks(n), BLOCK, 0, c->stream>>>(
                 c->key, c->cell_start, c->tmp_src, c->tmp_id, n, c->pos[s], c->vel[s],
-                c->prd[ps_], c->pos[d], c->vel[d], c->prd[pd], c->id[d]);
+                c->prd[ps_], c->pos[d], c->vel[d], c->prd[pd], c->id[d], c->slab ? c->slot_of : nullptr);
             c->cur = d;
             c->prd_cur = pd;
         }
@@ -1126,6 +1263,10 @@ int pbf_create(const pbf_params* params, int device, pbf_ctx** out) {
     CREATE_CK(hipMalloc(&c->staging, c->staging_bytes ? c->staging_bytes : 16));
     CREATE_CK(dalloc(&c->flags, 1));
     CREATE_CK(dalloc(&c->stat_partials, 1024));
+    CREATE_CK(dalloc(&c->slot_of, cap));
+    CREATE_CK(dalloc(&c->blist[0], cap));
+    CREATE_CK(dalloc(&c->blist[1], cap));
+    CREATE_CK(dalloc(&c->slab_cnt, 1));
     CREATE_CK(hipMemsetAsync(c->cell_count, 0, (size_t)c->ncell * 4, c->stream));
     CREATE_CK(hipMemsetAsync(c->flags, 0, sizeof(DevFlags), c->stream));
     CREATE_CK(hipMemsetAsync(c->nbr_count, 0, cap * 4, c->stream));
@@ -1169,7 +1310,11 @@ int pbf_destroy(pbf_ctx* c) {
     (void)hipFree(c->staging);
     (void)hipFree(c->flags);
     (void)hipFree(c->stat_partials);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    (void)hipFree(c->slot_of);
+    (void)hipFree(c->blist[0]);
+    (void)hipFree(c->blist[1]);
+    (void)hipFree(c->slab_cnt);
+    if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PBF_OK;
 }
@@ -1266,11 +1411,11 @@ int pbf_predict(pbf_ctx* c, float dt) {
     if (c->n) {
         PhaseScope ps(c, PH_PREDICT);
         k_predict<<<nblocks(c->n), BLOCK, 0, c->stream>>>(
-            c->pos[c->cur], c->vel[c->cur], c->prd[c->prd_cur], c->key, c->cell_count, c->n, dt,
+            c->pos[c->cur], c->vel[c->cur], c->prd[c->prd_cur], c->key, c->slab ? nullptr : c->cell_count, c->n, dt,
             c->P.gravity[0], c->P.gravity[1], c->P.gravity[2], c->colliders, make_grid(c->P));
         LAUNCH_CK(c);
     }
-    c->keyed = true;
+    c->keyed = !c->slab;
     c->grid_valid = false;
     return PBF_OK;
 }
@@ -1302,90 +1447,300 @@ int pbf_compute_rest_density(pbf_ctx* c) {
     return PBF_OK;
 }
 
-int pbf_solve(pbf_ctx* c, int32_t iterations, float dt) {
-    ENTER(c);
-    if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "pbf_build_grid must run first");
-    if (iterations <= 0) iterations = c->iterations;
-    if (!c->n) return PBF_OK;
+static int solve_half(pbf_ctx* c, int half, float dt) {
     const KernConsts kc = make_kern(c->P, dt);
-    float3_ cmin = {c->P.container_min[0], c->P.container_min[1], c->P.container_min[2]};
-    float3_ cmax = {c->P.container_max[0], c->P.container_max[1], c->P.container_max[2]};
     const uint32_t nb = nblocks(c->n);
     const bool spiky = c->P.gradient_kernel == PBF_GRAD_SPIKY;
-    for (int32_t it = 0; it < iterations; ++it) {
-        float4* x = c->prd[c->prd_cur];
-        float4* y = c->prd[(c->prd_cur + 1) % 3];
-        {
-            PhaseScope ps(c, PH_LAMBDA);
+    float4* x = c->prd[c->prd_cur];
+    if (half == 0) {
+        PhaseScope ps(c, PH_LAMBDA);
 #define LAUNCH_LAMBDA(U, G)                                                                   \
     k_lambda<U, G><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count, c->n, \
                                                 c->cap, kc, c->rho0, c->uniform_mass, c->dens, c->C)
-            if (c->uniform && !spiky) LAUNCH_LAMBDA(true, PBF_GRAD_POLY6);
-            else if (c->uniform) LAUNCH_LAMBDA(true, PBF_GRAD_SPIKY);
-            else if (!spiky) LAUNCH_LAMBDA(false, PBF_GRAD_POLY6);
-            else LAUNCH_LAMBDA(false, PBF_GRAD_SPIKY);
+        if (c->uniform && !spiky) LAUNCH_LAMBDA(true, PBF_GRAD_POLY6);
+        else if (c->uniform) LAUNCH_LAMBDA(true, PBF_GRAD_SPIKY);
+        else if (!spiky) LAUNCH_LAMBDA(false, PBF_GRAD_POLY6);
+        else LAUNCH_LAMBDA(false, PBF_GRAD_SPIKY);
 #undef LAUNCH_LAMBDA
-        }
-        {
-            PhaseScope ps(c, PH_DELTA);
-            if (!spiky)
-                k_delta<PBF_GRAD_POLY6><<<nb, BLOCK, 0, c->stream>>>(
-                    x, y, c->nbr, c->nbr_count, c->n, c->cap, kc, c->rho0, c->P.container_enabled,
-                    cmin, cmax);
-            else
-                k_delta<PBF_GRAD_SPIKY><<<nb, BLOCK, 0, c->stream>>>(
-                    x, y, c->nbr, c->nbr_count, c->n, c->cap, kc, c->rho0, c->P.container_enabled,
-                    cmin, cmax);
-        }
+    } else {
+        PhaseScope ps(c, PH_DELTA);
+        float3_ cmin = {c->P.container_min[0], c->P.container_min[1], c->P.container_min[2]};
+        float3_ cmax = {c->P.container_max[0], c->P.container_max[1], c->P.container_max[2]};
+        float4* y = c->prd[(c->prd_cur + 1) % 3];
+        if (!spiky)
+            k_delta<PBF_GRAD_POLY6><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n,
+                                                                 c->cap, kc, c->rho0,
+                                                                 c->P.container_enabled, cmin, cmax);
+        else
+            k_delta<PBF_GRAD_SPIKY><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n,
+                                                                 c->cap, kc, c->rho0,
+                                                                 c->P.container_enabled, cmin, cmax);
         c->prd_cur = (c->prd_cur + 1) % 3;
     }
     LAUNCH_CK(c);
     return PBF_OK;
 }
 
-int pbf_finalize(pbf_ctx* c, float dt) {
+int pbf_solve(pbf_ctx* c, int32_t iterations, float dt) {
     ENTER(c);
+    if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "pbf_build_grid must run first");
+    if (iterations <= 0) iterations = c->iterations;
     if (!c->n) return PBF_OK;
-    const uint32_t nb = nblocks(c->n);
-    {
-        PhaseScope ps(c, PH_FINALIZE);
-        k_finalize<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], c->vel[c->cur], c->prd[c->prd_cur],
-                                                c->n, dt);
-        LAUNCH_CK(c);
+    for (int32_t it = 0; it < iterations; ++it) {
+        int rc = solve_half(c, 0, dt);
+        if (rc) return rc;
+        if ((rc = solve_half(c, 1, dt))) return rc;
     }
-    if (c->P.vorticity_eps != 0.f || c->P.xsph_c != 0.f) {
-        if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "viscosity needs the neighbour table");
-        PhaseScope ps(c, PH_VISCOSITY);
-        const KernConsts kc = make_kern(c->P, dt);
-        // the spare velocity copy (the one the next sort will overwrite) is the Jacobi target
-        float4* va = c->vel[c->cur];
-        float4* vb = c->vel[1 - c->cur];
-        if (c->P.vorticity_eps != 0.f) {
-            if (c->P.gradient_kernel == PBF_GRAD_SPIKY) {
+    return PBF_OK;
+}
+
+int pbf_solve_lambda(pbf_ctx* c, float dt) {
+    ENTER(c);
+    if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "pbf_build_grid must run first");
+    return c->n ? solve_half(c, 0, dt) : PBF_OK;
+}
+
+int pbf_solve_delta(pbf_ctx* c, float dt) {
+    ENTER(c);
+    if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "pbf_build_grid must run first");
+    return c->n ? solve_half(c, 1, dt) : PBF_OK;
+}
+
+static int finalize_stage(pbf_ctx* c, int stage, float dt) {
+    const uint32_t nb = nblocks(c->n);
+    const KernConsts kc = make_kern(c->P, dt);
+    const bool spiky = c->P.gradient_kernel == PBF_GRAD_SPIKY;
+    float4* va = c->vel[c->cur];
+    float4* vb = c->vel[1 - c->cur];  // spare copy (the next sort overwrites it): Jacobi target
+    switch (stage) {
+        case 0: {
+            PhaseScope ps(c, PH_FINALIZE);
+            k_finalize<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], va, c->prd[c->prd_cur], c->n, dt);
+            break;
+        }
+        case 1: {
+            PhaseScope ps(c, PH_VISCOSITY);
+            if (spiky)
                 k_vorticity<PBF_GRAD_SPIKY><<<nb, BLOCK, 0, c->stream>>>(
                     c->pos[c->cur], va, c->nbr, c->nbr_count, c->n, c->cap, kc, c->omega);
+            else
+                k_vorticity<PBF_GRAD_POLY6><<<nb, BLOCK, 0, c->stream>>>(
+                    c->pos[c->cur], va, c->nbr, c->nbr_count, c->n, c->cap, kc, c->omega);
+            break;
+        }
+        case 2: {
+            PhaseScope ps(c, PH_VISCOSITY);
+            if (spiky)
                 k_vorticity_apply<PBF_GRAD_SPIKY><<<nb, BLOCK, 0, c->stream>>>(
                     c->pos[c->cur], va, c->omega, c->nbr, c->nbr_count, c->n, c->cap, kc, c->rho0,
                     dt, c->P.vorticity_eps, vb);
-            } else {
-                k_vorticity<PBF_GRAD_POLY6><<<nb, BLOCK, 0, c->stream>>>(
-                    c->pos[c->cur], va, c->nbr, c->nbr_count, c->n, c->cap, kc, c->omega);
+            else
                 k_vorticity_apply<PBF_GRAD_POLY6><<<nb, BLOCK, 0, c->stream>>>(
                     c->pos[c->cur], va, c->omega, c->nbr, c->nbr_count, c->n, c->cap, kc, c->rho0,
                     dt, c->P.vorticity_eps, vb);
-            }
-            float4* t = va; va = vb; vb = t;
+            c->vel[c->cur] = vb;  // the two velocity copies trade places
+            c->vel[1 - c->cur] = va;
+            break;
         }
-        if (c->P.xsph_c != 0.f) {
+        case 3: {
+            PhaseScope ps(c, PH_VISCOSITY);
             k_xsph<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], va, c->nbr, c->nbr_count, c->n,
                                                 c->cap, kc, c->rho0, c->P.xsph_c, vb);
-            float4* t = va; va = vb; vb = t;
+            c->vel[c->cur] = vb;
+            c->vel[1 - c->cur] = va;
+            break;
         }
-        if (va != c->vel[c->cur])
-            HIP_CK(c, hipMemcpyAsync(c->vel[c->cur], va, (size_t)c->n * 16, hipMemcpyDeviceToDevice,
-                                     c->stream));
+        default:
+            return fail(c, PBF_ERR_INVALID, "bad finalize stage");
+    }
+    LAUNCH_CK(c);
+    return PBF_OK;
+}
+
+int pbf_finalize_stage(pbf_ctx* c, int32_t stage, float dt) {
+    ENTER(c);
+    if (!c->n) return PBF_OK;
+    if (stage > 0 && !c->grid_valid) return fail(c, PBF_ERR_INVALID, "viscosity needs the neighbour table");
+    return finalize_stage(c, stage, dt);
+}
+
+int pbf_finalize(pbf_ctx* c, float dt) {
+    ENTER(c);
+    if (!c->n) return PBF_OK;
+    int rc = finalize_stage(c, 0, dt);
+    if (rc) return rc;
+    if (c->P.vorticity_eps != 0.f || c->P.xsph_c != 0.f) {
+        if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "viscosity needs the neighbour table");
+        if (c->P.vorticity_eps != 0.f) {
+            if ((rc = finalize_stage(c, 1, dt))) return rc;
+            if ((rc = finalize_stage(c, 2, dt))) return rc;
+        }
+        if (c->P.xsph_c != 0.f && (rc = finalize_stage(c, 3, dt))) return rc;
+    }
+    return PBF_OK;
+}
+
+// ---------------------------------------------------------------- slab decomposition
+
+int pbf_set_stream(pbf_ctx* c, void* stream) {
+    ENTER(c);
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    fold_spans(c);
+    if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)stream;
+    c->owns_stream = false;
+    return PBF_OK;
+}
+
+int pbf_slab_set_bounds(pbf_ctx* c, int32_t x_lo, int32_t x_hi) {
+    if (!c) return PBF_ERR_INVALID;
+    if (x_lo >= x_hi) return fail(c, PBF_ERR_INVALID, "empty slab");
+    if (c->P.rest_density_mode != PBF_RHO0_FIXED)
+        return fail(c, PBF_ERR_INVALID, "slab mode needs PBF_RHO0_FIXED (the first-frame mean is a serial global sum)");
+    c->slab = true;
+    c->x_lo = x_lo;
+    c->x_hi = x_hi;
+    return PBF_OK;
+}
+
+int pbf_slab_partition(pbf_ctx* c, void* d_left, void* d_right, uint32_t max_records,
+                       uint32_t counts[3]) {
+    ENTER(c);
+    if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
+    if (!counts) return fail(c, PBF_ERR_INVALID, "null counts");
+    HIP_CK(c, hipMemsetAsync(c->slab_cnt, 0, sizeof(SlabCounters), c->stream));
+    const int s = c->cur, d = 1 - c->cur;
+    const int ps_ = c->prd_cur, pd = (c->prd_cur + 1) % 3;
+    if (c->n) {
+        k_slab_partition<<<nblocks(c->n), BLOCK, 0, c->stream>>>(
+            c->pos[s], c->vel[s], c->prd[ps_], c->id[s], c->n, c->P.grid_spacing, c->x_lo, c->x_hi,
+            c->pos[d], c->vel[d], c->prd[pd], c->id[d], (float*)d_left, (float*)d_right, max_records,
+            c->slab_cnt);
         LAUNCH_CK(c);
     }
+    SlabCounters h;
+    HIP_CK(c, hipMemcpyAsync(&h, c->slab_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    if (h.left > max_records || h.right > max_records)
+        return fail(c, PBF_ERR_CAPACITY, "migration buffer too small");
+    c->cur = d;
+    c->prd_cur = pd;
+    c->n = h.stay;
+    c->keyed = false;
+    c->grid_valid = false;
+    c->ghost_count[0] = c->ghost_count[1] = 0;
+    c->bcount[0] = c->bcount[1] = 0;
+    counts[0] = h.stay;
+    counts[1] = h.left;
+    counts[2] = h.right;
+    return PBF_OK;
+}
+
+int pbf_slab_append(pbf_ctx* c, const void* d_records, uint32_t count, int32_t ghost_side) {
+    ENTER(c);
+    if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
+    if (ghost_side < -1 || ghost_side > 1) return fail(c, PBF_ERR_INVALID, "bad ghost_side");
+    if ((uint64_t)c->n + count > c->cap) return fail(c, PBF_ERR_CAPACITY, "slab exceeds ctx capacity");
+    if (ghost_side >= 0) {
+        c->ghost_base[ghost_side] = c->n;
+        c->ghost_count[ghost_side] = count;
+    } else if (c->ghost_count[0] || c->ghost_count[1]) {
+        return fail(c, PBF_ERR_INVALID, "owned particles must be appended before ghosts");
+    }
+    if (count) {
+        if (!d_records) return fail(c, PBF_ERR_INVALID, "null records");
+        k_slab_append<<<nblocks(count), BLOCK, 0, c->stream>>>(
+            (const float*)d_records, count, c->n, ghost_side >= 0 ? GHOST_BIT : 0u, c->pos[c->cur],
+            c->vel[c->cur], c->prd[c->prd_cur], c->id[c->cur]);
+        LAUNCH_CK(c);
+    }
+    c->n += count;
+    c->grid_valid = false;
+    return PBF_OK;
+}
+
+int pbf_slab_pack_ghosts(pbf_ctx* c, int32_t side, void* d_out, uint32_t max_records,
+                         uint32_t* count) {
+    ENTER(c);
+    if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
+    if (side < 0 || side > 1 || !count) return fail(c, PBF_ERR_INVALID, "bad argument");
+    *count = 0;
+    c->bcount[side] = 0;
+    const int32_t plane = side == 0 ? c->x_lo : c->x_hi - 1;
+    const bool open_end = side == 0 ? c->x_lo == INT32_MIN : c->x_hi == INT32_MAX;
+    if (open_end || !c->n) return PBF_OK;
+    uint32_t* counter = &c->slab_cnt->ghosts;
+    HIP_CK(c, hipMemsetAsync(counter, 0, 4, c->stream));
+    if (max_records > c->cap) max_records = c->cap;
+    k_slab_pack_ghosts<<<nblocks(c->n), BLOCK, 0, c->stream>>>(
+        c->pos[c->cur], c->vel[c->cur], c->prd[c->prd_cur], c->id[c->cur], c->n, c->P.grid_spacing,
+        plane, (float*)d_out, max_records, c->blist[side], counter);
+    LAUNCH_CK(c);
+    uint32_t h = 0;
+    HIP_CK(c, hipMemcpyAsync(&h, counter, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    if (h > max_records) return fail(c, PBF_ERR_CAPACITY, "ghost buffer too small");
+    c->bcount[side] = h;
+    *count = h;
+    return PBF_OK;
+}
+
+static float4* halo_array(pbf_ctx* c, int32_t what) {
+    switch (what) {
+        case 0: return c->prd[c->prd_cur];
+        case 1: return c->vel[c->cur];
+        case 2: return c->omega;
+        case 3: return c->pos[c->cur];
+        default: return nullptr;
+    }
+}
+
+int pbf_slab_pack_halo(pbf_ctx* c, int32_t side, int32_t what, void* d_out) {
+    ENTER(c);
+    if (!c->slab || !c->grid_valid) return fail(c, PBF_ERR_INVALID, "halo refresh needs a built slab grid");
+    float4* src = halo_array(c, what);
+    if (side < 0 || side > 1 || !src) return fail(c, PBF_ERR_INVALID, "bad argument");
+    const uint32_t k = c->bcount[side];
+    if (!k) return PBF_OK;
+    if (!d_out) return fail(c, PBF_ERR_INVALID, "null buffer");
+    k_slab_pack_halo<<<nblocks(k), BLOCK, 0, c->stream>>>(src, c->blist[side], c->slot_of, k, (float4*)d_out);
+    LAUNCH_CK(c);
+    return PBF_OK;
+}
+
+int pbf_slab_unpack_halo(pbf_ctx* c, int32_t side, int32_t what, const void* d_in, uint32_t count) {
+    ENTER(c);
+    if (!c->slab || !c->grid_valid) return fail(c, PBF_ERR_INVALID, "halo refresh needs a built slab grid");
+    float4* dst = halo_array(c, what);
+    if (side < 0 || side > 1 || !dst) return fail(c, PBF_ERR_INVALID, "bad argument");
+    if (count != c->ghost_count[side]) return fail(c, PBF_ERR_INVALID, "halo size differs from the ghost count");
+    if (!count) return PBF_OK;
+    if (!d_in) return fail(c, PBF_ERR_INVALID, "null buffer");
+    // positions keep their own mass in .w; everything else is replaced whole
+    k_slab_unpack_halo<<<nblocks(count), BLOCK, 0, c->stream>>>(dst, c->slot_of, c->ghost_base[side],
+                                                              count, (const float4*)d_in, what == 3);
+    LAUNCH_CK(c);
+    return PBF_OK;
+}
+
+int pbf_slab_export(pbf_ctx* c, void* d_records, uint32_t max_records, uint32_t* count) {
+    ENTER(c);
+    if (!count) return fail(c, PBF_ERR_INVALID, "null count");
+    *count = 0;
+    if (!c->slab_cnt) return fail(c, PBF_ERR_INVALID, "ctx not initialised");
+    uint32_t* counter = &c->slab_cnt->exported;
+    HIP_CK(c, hipMemsetAsync(counter, 0, 4, c->stream));
+    if (c->n) {
+        k_slab_export<<<nblocks(c->n), BLOCK, 0, c->stream>>>(c->pos[c->cur], c->vel[c->cur],
+                                                            c->prd[c->prd_cur], c->id[c->cur], c->n,
+                                                            (float*)d_records, max_records, counter);
+        LAUNCH_CK(c);
+    }
+    uint32_t h = 0;
+    HIP_CK(c, hipMemcpyAsync(&h, counter, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    if (h > max_records) return fail(c, PBF_ERR_CAPACITY, "export buffer too small");
+    *count = h;
     return PBF_OK;
 }
 
@@ -1412,6 +1767,7 @@ int pbf_sync(pbf_ctx* c) {
 
 int pbf_download(pbf_ctx* c, float* pos, float* vel, float* pred) {
     ENTER(c);
+    if (c->slab) return fail(c, PBF_ERR_INVALID, "id-indexed read-back is not available in slab mode (ids are global): use pbf_slab_export");
     int rc = download3(c, c->pos[c->cur], pos);
     if (rc) return rc;
     rc = download3(c, c->vel[c->cur], vel);
@@ -1424,6 +1780,7 @@ int pbf_download(pbf_ctx* c, float* pos, float* vel, float* pred) {
 
 int pbf_get_scalars(pbf_ctx* c, float* density, float* C, float* lambda) {
     ENTER(c);
+    if (c->slab) return fail(c, PBF_ERR_INVALID, "id-indexed read-back is not available in slab mode (ids are global): use pbf_slab_export");
     const uint32_t n = c->n;
     if (!n) return PBF_OK;
     // staging holds cap*16 B: three cap-float planes fit
@@ -1442,6 +1799,7 @@ int pbf_get_scalars(pbf_ctx* c, float* density, float* C, float* lambda) {
 int pbf_get_cells(pbf_ctx* c, int32_t* cell_xyz, uint32_t* cell_key_out, uint32_t* sorted_id,
                   uint32_t* cell_start) {
     ENTER(c);
+    if (c->slab) return fail(c, PBF_ERR_INVALID, "id-indexed read-back is not available in slab mode (ids are global): use pbf_slab_export");
     if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "pbf_build_grid must run first");
     const uint32_t n = c->n;
     if (n && (cell_xyz || cell_key_out)) {
@@ -1464,6 +1822,7 @@ int pbf_get_cells(pbf_ctx* c, int32_t* cell_xyz, uint32_t* cell_key_out, uint32_
 
 int pbf_get_neighbors(pbf_ctx* c, uint32_t* counts, uint32_t* neighbors, uint32_t stride) {
     ENTER(c);
+    if (c->slab) return fail(c, PBF_ERR_INVALID, "id-indexed read-back is not available in slab mode (ids are global): use pbf_slab_export");
     if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "pbf_build_grid must run first");
     if (!counts || !neighbors || stride == 0) return fail(c, PBF_ERR_INVALID, "null output");
     const uint32_t n = c->n;
@@ -1500,7 +1859,7 @@ int pbf_get_stats(pbf_ctx* c, pbf_stats* out) {
     if (nb > 1024) nb = 1024;
     std::vector<StatPartial> parts(nb);
     if (c->n) {
-        k_stats<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], c->vel[c->cur], c->C, c->nbr_count, c->n,
+        k_stats<<<nb, BLOCK, 0, c->stream>>>(c->pos[c->cur], c->vel[c->cur], c->C, c->nbr_count, c->id[c->cur], c->n,
                                              c->stat_partials);
         LAUNCH_CK(c);
         HIP_CK(c, hipMemcpyAsync(parts.data(), c->stat_partials, nb * sizeof(StatPartial),

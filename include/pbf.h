@@ -196,6 +196,41 @@ int pbf_get_stats(pbf_ctx* ctx, pbf_stats* out);
 int pbf_get_rest_density(pbf_ctx* ctx, float* out);
 uint32_t pbf_num_particles(const pbf_ctx* ctx);
 
+/* the two halves of one solver iteration (pbf_solve == iterations x {lambda, delta}) and the
+ * stages of pbf_finalize (0 = ParticleSet::Update, 1 = vorticity omega, 2 = vorticity apply,
+ * 3 = XSPH), exposed so that a slab-decomposed caller can refresh ghost data in between */
+int pbf_solve_lambda(pbf_ctx* ctx, float dt);
+int pbf_solve_delta(pbf_ctx* ctx, float dt);
+int pbf_finalize_stage(pbf_ctx* ctx, int32_t stage, float dt);
+
+/* ---- slab decomposition over the GPUs of one node.  No counterpart in the
+ * reference, which is single-GPU (cuda_simulation.cu has no multi-device code).  A ctx owns
+ * the cells whose x index is in [x_lo, x_hi); neighbours exchange particle records of
+ * PBF_RECORD_FLOATS floats: pos.xyz, mass, vel.xyz, id (as bits), pred.xyz, 0.  All buffers
+ * are DEVICE pointers owned by the caller (e.g. torch tensors handed to RCCL). */
+#define PBF_RECORD_FLOATS 12
+enum { PBF_HALO_PRED_LAMBDA = 0, PBF_HALO_VELOCITY = 1, PBF_HALO_OMEGA = 2, PBF_HALO_POSITION = 3 };
+/* run this ctx's kernels on the caller's HIP stream (hipStream_t) instead of its own */
+int pbf_set_stream(pbf_ctx* ctx, void* hip_stream);
+/* INT32_MIN / INT32_MAX mark an open end; requires PBF_RHO0_FIXED */
+int pbf_slab_set_bounds(pbf_ctx* ctx, int32_t x_lo, int32_t x_hi);
+/* after pbf_predict: drops last step's ghosts, keeps the particles whose predicted cell is still
+ * owned, packs the others into d_left / d_right; counts = {stay, left, right} (synchronises) */
+int pbf_slab_partition(pbf_ctx* ctx, void* d_left, void* d_right, uint32_t max_records,
+                       uint32_t counts[3]);
+/* appends records: ghost_side -1 = owned (migrants, initial population), 0 / 1 = ghosts
+ * received from the left / right neighbour (owned first, then ghosts) */
+int pbf_slab_append(pbf_ctx* ctx, const void* d_records, uint32_t count, int32_t ghost_side);
+/* packs the owned particles of the boundary cell plane (side 0: x_lo, side 1: x_hi - 1) for the
+ * neighbour on that side and remembers them for the halo refreshes (synchronises) */
+int pbf_slab_pack_ghosts(pbf_ctx* ctx, int32_t side, void* d_out, uint32_t max_records,
+                         uint32_t* count);
+/* after pbf_build_grid: one float4 per boundary-plane particle / per ghost, in pack order */
+int pbf_slab_pack_halo(pbf_ctx* ctx, int32_t side, int32_t what, void* d_out);
+int pbf_slab_unpack_halo(pbf_ctx* ctx, int32_t side, int32_t what, const void* d_in, uint32_t count);
+/* all owned particles as records, arbitrary order (synchronises) */
+int pbf_slab_export(pbf_ctx* ctx, void* d_records, uint32_t max_records, uint32_t* count);
+
 /* per-phase device time of the kernels launched by this ctx, measured with HIP events on
  * the ctx stream when enabled (replaces the ImGui chrono panel, Simulation.cpp:126-133).
  * phase names: pbf_phase_name(i), i < pbf_num_phases(). ms[i] accumulates, calls[i] counts. */

@@ -700,88 +700,100 @@ int orc_update_predict_position(orc_ctx* c) {
  *   eta_i   = sum_j (m_j / rho0) |omega_j| gradW(p_i - p_j);  N = eta / |eta|
  *   v_i    += dt * eps_v * (N x omega_i)
  *   v_i    <- v_i + c * sum_j (m_j / rho0) (v_j - v_i) W(|p_i - p_j|)      (Jacobi) */
-static void vorticity_xsph(orc_ctx* c, float dt) {
+int orc_vorticity_omega(orc_ctx* c) {
+    if (!c) return PBF_ERR_INVALID;
+    const int n = (int)c->n;
+    const kern_t k = make_kern(c->P.effective_radius, c->P.gradient_kernel);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(c->threads)
+    for (int i = 0; i < n; ++i) {
+        const float* pi = c->pos + 3 * i;
+        const float* vi = c->vel + 3 * i;
+        float w[3] = {0, 0, 0};
+        for (uint64_t a = c->nbr_off[i]; a < c->nbr_off[i + 1]; ++a) {
+            uint32_t j = c->nbr[a];
+            const float* pj = c->pos + 3 * j;
+            const float* vj = c->vel + 3 * j;
+            float diff[3] = {pi[0] - pj[0], pi[1] - pj[1], pi[2] - pj[2]};
+            float distance = dist3(pi, pj);
+            float g[3];
+            k_grad(&k, diff, distance, g);
+            float u[3] = {vj[0] - vi[0], vj[1] - vi[1], vj[2] - vi[2]};
+            w[0] += u[1] * g[2] - g[1] * u[2];
+            w[1] += u[2] * g[0] - g[2] * u[0];
+            w[2] += u[0] * g[1] - g[0] * u[1];
+        }
+        c->omega[3 * i] = w[0]; c->omega[3 * i + 1] = w[1]; c->omega[3 * i + 2] = w[2];
+    }
+    return PBF_OK;
+}
+
+int orc_vorticity_apply(orc_ctx* c, float dt) {
+    if (!c) return PBF_ERR_INVALID;
     const int n = (int)c->n;
     const kern_t k = make_kern(c->P.effective_radius, c->P.gradient_kernel);
     const float inv_rho0 = 1.f / c->rest_density;
-    if (c->P.vorticity_eps != 0.f) {
+    const float eps_v = c->P.vorticity_eps;
 #pragma omp parallel for schedule(dynamic, 64) num_threads(c->threads)
-        for (int i = 0; i < n; ++i) {
-            const float* pi = c->pos + 3 * i;
-            const float* vi = c->vel + 3 * i;
-            float w[3] = {0, 0, 0};
-            for (uint64_t a = c->nbr_off[i]; a < c->nbr_off[i + 1]; ++a) {
-                uint32_t j = c->nbr[a];
-                const float* pj = c->pos + 3 * j;
-                const float* vj = c->vel + 3 * j;
-                float diff[3] = {pi[0] - pj[0], pi[1] - pj[1], pi[2] - pj[2]};
-                float distance = dist3(pi, pj);
-                float g[3];
-                k_grad(&k, diff, distance, g);
-                float u[3] = {vj[0] - vi[0], vj[1] - vi[1], vj[2] - vi[2]};
-                w[0] += u[1] * g[2] - g[1] * u[2];
-                w[1] += u[2] * g[0] - g[2] * u[0];
-                w[2] += u[0] * g[1] - g[0] * u[1];
-            }
-            c->omega[3 * i] = w[0]; c->omega[3 * i + 1] = w[1]; c->omega[3 * i + 2] = w[2];
+    for (int i = 0; i < n; ++i) {
+        const float* pi = c->pos + 3 * i;
+        float eta[3] = {0, 0, 0};
+        for (uint64_t a = c->nbr_off[i]; a < c->nbr_off[i + 1]; ++a) {
+            uint32_t j = c->nbr[a];
+            const float* pj = c->pos + 3 * j;
+            float diff[3] = {pi[0] - pj[0], pi[1] - pj[1], pi[2] - pj[2]};
+            float distance = dist3(pi, pj);
+            float g[3];
+            k_grad(&k, diff, distance, g);
+            const float* wj = c->omega + 3 * j;
+            float s = (c->mass[j] * inv_rho0) * sqrtf(dot3(wj, wj));
+            eta[0] += s * g[0]; eta[1] += s * g[1]; eta[2] += s * g[2];
         }
-        const float eps_v = c->P.vorticity_eps;
-#pragma omp parallel for schedule(dynamic, 64) num_threads(c->threads)
-        for (int i = 0; i < n; ++i) {
-            const float* pi = c->pos + 3 * i;
-            float eta[3] = {0, 0, 0};
-            for (uint64_t a = c->nbr_off[i]; a < c->nbr_off[i + 1]; ++a) {
-                uint32_t j = c->nbr[a];
-                const float* pj = c->pos + 3 * j;
-                float diff[3] = {pi[0] - pj[0], pi[1] - pj[1], pi[2] - pj[2]};
-                float distance = dist3(pi, pj);
-                float g[3];
-                k_grad(&k, diff, distance, g);
-                const float* wj = c->omega + 3 * j;
-                float s = (c->mass[j] * inv_rho0) * sqrtf(dot3(wj, wj));
-                eta[0] += s * g[0]; eta[1] += s * g[1]; eta[2] += s * g[2];
-            }
-            float len = sqrtf(dot3(eta, eta));
-            float* v2 = c->vel2 + 3 * i;
-            const float* v = c->vel + 3 * i;
-            v2[0] = v[0]; v2[1] = v[1]; v2[2] = v[2];
-            if (len > 0.f) {
-                float N[3] = {eta[0] / len, eta[1] / len, eta[2] / len};
-                const float* w = c->omega + 3 * i;
-                float f[3] = {N[1] * w[2] - w[1] * N[2], N[2] * w[0] - w[2] * N[0],
-                              N[0] * w[1] - w[0] * N[1]};
-                float s = dt * eps_v;
-                v2[0] = v[0] + s * f[0]; v2[1] = v[1] + s * f[1]; v2[2] = v[2] + s * f[2];
-            }
+        float len = sqrtf(dot3(eta, eta));
+        float* v2 = c->vel2 + 3 * i;
+        const float* v = c->vel + 3 * i;
+        v2[0] = v[0]; v2[1] = v[1]; v2[2] = v[2];
+        if (len > 0.f) {
+            float N[3] = {eta[0] / len, eta[1] / len, eta[2] / len};
+            const float* w = c->omega + 3 * i;
+            float f[3] = {N[1] * w[2] - w[1] * N[2], N[2] * w[0] - w[2] * N[0],
+                          N[0] * w[1] - w[0] * N[1]};
+            float s = dt * eps_v;
+            v2[0] = v[0] + s * f[0]; v2[1] = v[1] + s * f[1]; v2[2] = v[2] + s * f[2];
         }
-        memcpy(c->vel, c->vel2, (size_t)n * 12);
     }
-    if (c->P.xsph_c != 0.f) {
-        const float cx = c->P.xsph_c;
-#pragma omp parallel for schedule(dynamic, 64) num_threads(c->threads)
-        for (int i = 0; i < n; ++i) {
-            const float* pi = c->pos + 3 * i;
-            const float* vi = c->vel + 3 * i;
-            float acc[3] = {0, 0, 0};
-            for (uint64_t a = c->nbr_off[i]; a < c->nbr_off[i + 1]; ++a) {
-                uint32_t j = c->nbr[a];
-                const float* pj = c->pos + 3 * j;
-                const float* vj = c->vel + 3 * j;
-                float distance = dist3(pi, pj);
-                float s = (c->mass[j] * inv_rho0) * k_poly6(&k, distance);
-                acc[0] += s * (vj[0] - vi[0]); acc[1] += s * (vj[1] - vi[1]);
-                acc[2] += s * (vj[2] - vi[2]);
-            }
-            float* v2 = c->vel2 + 3 * i;
-            v2[0] = vi[0] + cx * acc[0]; v2[1] = vi[1] + cx * acc[1]; v2[2] = vi[2] + cx * acc[2];
-        }
-        memcpy(c->vel, c->vel2, (size_t)n * 12);
-    }
+    memcpy(c->vel, c->vel2, (size_t)n * 12);
+    return PBF_OK;
 }
 
-/* Simulation::ApplySolverResults -> ParticleSet::Update, Simulation.cpp:787-791,
- * Particle.cpp:207-215 (true division by dt) */
-int orc_apply_solver_results(orc_ctx* c, float dt) {
+int orc_xsph(orc_ctx* c) {
+    if (!c) return PBF_ERR_INVALID;
+    const int n = (int)c->n;
+    const kern_t k = make_kern(c->P.effective_radius, c->P.gradient_kernel);
+    const float inv_rho0 = 1.f / c->rest_density;
+    const float cx = c->P.xsph_c;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(c->threads)
+    for (int i = 0; i < n; ++i) {
+        const float* pi = c->pos + 3 * i;
+        const float* vi = c->vel + 3 * i;
+        float acc[3] = {0, 0, 0};
+        for (uint64_t a = c->nbr_off[i]; a < c->nbr_off[i + 1]; ++a) {
+            uint32_t j = c->nbr[a];
+            const float* pj = c->pos + 3 * j;
+            const float* vj = c->vel + 3 * j;
+            float distance = dist3(pi, pj);
+            float s = (c->mass[j] * inv_rho0) * k_poly6(&k, distance);
+            acc[0] += s * (vj[0] - vi[0]); acc[1] += s * (vj[1] - vi[1]);
+            acc[2] += s * (vj[2] - vi[2]);
+        }
+        float* v2 = c->vel2 + 3 * i;
+        v2[0] = vi[0] + cx * acc[0]; v2[1] = vi[1] + cx * acc[1]; v2[2] = vi[2] + cx * acc[2];
+    }
+    memcpy(c->vel, c->vel2, (size_t)n * 12);
+    return PBF_OK;
+}
+
+/* ParticleSet::Update, Particle.cpp:207-215 (true division by dt) */
+int orc_update_velocity(orc_ctx* c, float dt) {
     if (!c) return PBF_ERR_INVALID;
     const int n = (int)c->n;
 #pragma omp parallel for schedule(static) num_threads(c->threads)
@@ -792,7 +804,19 @@ int orc_apply_solver_results(orc_ctx* c, float dt) {
         v[0] = (np[0] - p[0]) / dt; v[1] = (np[1] - p[1]) / dt; v[2] = (np[2] - p[2]) / dt;
         p[0] = np[0]; p[1] = np[1]; p[2] = np[2];
     }
-    if (c->P.vorticity_eps != 0.f || c->P.xsph_c != 0.f) vorticity_xsph(c, dt);
+    return PBF_OK;
+}
+
+/* Simulation::ApplySolverResults -> ParticleSet::Update, Simulation.cpp:787-791,
+ * Particle.cpp:207-215 (true division by dt) */
+int orc_apply_solver_results(orc_ctx* c, float dt) {
+    if (!c) return PBF_ERR_INVALID;
+    orc_update_velocity(c, dt);
+    if (c->P.vorticity_eps != 0.f) {
+        orc_vorticity_omega(c);
+        orc_vorticity_apply(c, dt);
+    }
+    if (c->P.xsph_c != 0.f) orc_xsph(c);
     return PBF_OK;
 }
 
@@ -904,6 +928,38 @@ int orc_get_stats(orc_ctx* c, pbf_stats* s) {
     s->max_abs_C = mx;
     if (msum > 0) { s->com[0] = com[0] / msum; s->com[1] = com[1] / msum; s->com[2] = com[2] / msum; }
     s->max_speed = vmax;
+    return PBF_OK;
+}
+
+/* raw array access for the slab-decomposition tests: 0 pos, 1 vel, 2 pred (== new), 3 lambda,
+ * 4 omega */
+static float* orc_array(orc_ctx* c, int which, int* width) {
+    switch (which) {
+        case 0: *width = 3; return c->pos;
+        case 1: *width = 3; return c->vel;
+        case 2: *width = 3; return c->pred;
+        case 3: *width = 1; return c->lambda;
+        case 4: *width = 3; return c->omega;
+        default: *width = 0; return NULL;
+    }
+}
+
+int orc_set_array(orc_ctx* c, int which, const float* data) {
+    int w;
+    if (!c || !data) return PBF_ERR_INVALID;
+    float* a = orc_array(c, which, &w);
+    if (!a) return PBF_ERR_INVALID;
+    memcpy(a, data, (size_t)c->n * w * 4);
+    if (which == 2) memcpy(c->newp, data, (size_t)c->n * 12);
+    return PBF_OK;
+}
+
+int orc_get_array(orc_ctx* c, int which, float* data) {
+    int w;
+    if (!c || !data) return PBF_ERR_INVALID;
+    float* a = orc_array(c, which, &w);
+    if (!a) return PBF_ERR_INVALID;
+    memcpy(data, a, (size_t)c->n * w * 4);
     return PBF_OK;
 }
 

@@ -49,6 +49,14 @@ int orc_compute_correction(orc_ctx* ctx, float dt);      /* Simulation.cpp:681-7
 int orc_update_predict_position(orc_ctx* ctx);           /* Simulation.cpp:714-721 */
 int orc_apply_solver_results(orc_ctx* ctx, float dt);    /* Simulation.cpp:787-791 */
 int orc_step(orc_ctx* ctx, float dt);                    /* Simulation.cpp:80-138 */
+/* the stages of orc_apply_solver_results, and raw array access (0 pos, 1 vel, 2 pred == new,
+ * 3 lambda, 4 omega), for the slab-decomposition tests */
+int orc_update_velocity(orc_ctx* ctx, float dt);         /* Particle.cpp:207-215 */
+int orc_vorticity_omega(orc_ctx* ctx);
+int orc_vorticity_apply(orc_ctx* ctx, float dt);
+int orc_xsph(orc_ctx* ctx);
+int orc_set_array(orc_ctx* ctx, int which, const float* data);
+int orc_get_array(orc_ctx* ctx, int which, float* data);
 
 int orc_download(orc_ctx* ctx, float* pos, float* vel, float* pred, float* newp);
 int orc_get_scalars(orc_ctx* ctx, float* density, float* C, float* lambda);

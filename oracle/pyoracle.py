@@ -55,6 +55,12 @@ def load():
     for name in ("orc_spatial_search", "orc_naive_search", "orc_compute_rest_density",
                  "orc_compute_density", "orc_compute_lambdas", "orc_update_predict_position"):
         getattr(lib, name).argtypes = [vp]
+    lib.orc_update_velocity.argtypes = [vp, C.c_float]
+    lib.orc_vorticity_omega.argtypes = [vp]
+    lib.orc_vorticity_apply.argtypes = [vp, C.c_float]
+    lib.orc_xsph.argtypes = [vp]
+    lib.orc_set_array.argtypes = [vp, C.c_int, vp]
+    lib.orc_get_array.argtypes = [vp, C.c_int, vp]
     lib.orc_download.argtypes = [vp, vp, vp, vp, vp]
     lib.orc_get_scalars.argtypes = [vp, vp, vp, vp]
     lib.orc_get_cells.argtypes = [vp, vp, vp]
@@ -205,6 +211,31 @@ class Oracle:
 
     def step(self, dt):
         self._ck(self.lib.orc_step(self._h, C.c_float(dt)))
+
+    def update_velocity(self, dt):
+        self._ck(self.lib.orc_update_velocity(self._h, C.c_float(dt)))
+
+    def vorticity_omega(self):
+        self._ck(self.lib.orc_vorticity_omega(self._h))
+
+    def vorticity_apply(self, dt):
+        self._ck(self.lib.orc_vorticity_apply(self._h, C.c_float(dt)))
+
+    def xsph(self):
+        self._ck(self.lib.orc_xsph(self._h))
+
+    ARRAYS = {"pos": (0, 3), "vel": (1, 3), "pred": (2, 3), "lambda": (3, 1), "omega": (4, 3)}
+
+    def set_array(self, name, data):
+        which, w = self.ARRAYS[name]
+        data = np.ascontiguousarray(data, dtype=np.float32).reshape(self.n, w)
+        self._ck(self.lib.orc_set_array(self._h, which, _ptr(data)))
+
+    def get_array(self, name):
+        which, w = self.ARRAYS[name]
+        out = np.empty((self.n, w), np.float32)
+        self._ck(self.lib.orc_get_array(self._h, which, _ptr(out)))
+        return out
 
     def download(self):
         n = self.n

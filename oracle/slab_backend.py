@@ -1,0 +1,170 @@
+"""CPU stand-in for one slab, built on the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Implements the backend interface that fluidsimulation_amd.slab.SlabGroup drives (the same
+protocol the HIP backend runs on the GPU) with numpy + the oracle's sub-step functions, so the
+decomposition protocol -- migration, ghost planes, halo refreshes -- can be exercised on CPU
+(in-process and over gloo with world_size 2) and compared with a single-domain oracle run.
+
+Local particles are kept sorted by GLOBAL id, so the oracle's bucket order (ascending local
+index, NeighborSearch.cpp:154-185) equals the single-domain order and results are bit-identical.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from fluidsimulation_amd.slab import (HALO_OMEGA, HALO_POSITION, HALO_PRED_LAMBDA, HALO_VELOCITY,
+                                      REC, cell_x, make_records, record_ids)
+from oracle import pyoracle
+
+
+class OracleSlabBackend:
+    def __init__(self, params, colliders, uniform_mass, x_lo, x_hi, threads=2):
+        self.params = params.copy()
+        self.cols = colliders
+        self.mass = np.float32(uniform_mass)
+        self.x_lo, self.x_hi = x_lo, x_hi
+        self.threads = threads
+        self.spacing = np.float32(params.grid_spacing)
+        e3 = np.zeros((0, 3), np.float32)
+        self.ids = np.zeros(0, np.uint32)
+        self.pos, self.vel, self.pred = e3.copy(), e3.copy(), e3.copy()
+        self.gid = [np.zeros(0, np.uint32), np.zeros(0, np.uint32)]
+        self.grec = [np.zeros((0, REC), np.float32), np.zeros((0, REC), np.float32)]
+        self.bids = [np.zeros(0, np.uint32), np.zeros(0, np.uint32)]
+        self.gcount = [0, 0]
+        self.o = None
+        self.viscous = params.xsph_c != 0.0 or params.vorticity_eps != 0.0
+        self.vorticity = params.vorticity_eps != 0.0
+        self.xsph = params.xsph_c != 0.0
+
+    # -- tensors
+    def to_backend(self, rec_np):
+        return torch.from_numpy(np.ascontiguousarray(rec_np, np.float32))
+
+    def empty(self, n, width):
+        return torch.empty((n, width), dtype=torch.float32)
+
+    def _oracle(self, pos, vel):
+        o = pyoracle.Oracle(self.params, threads=self.threads)
+        o.upload(pos, vel=vel, uniform_mass=float(self.mass))
+        o.set_colliders(self.cols)
+        return o
+
+    # -- protocol
+    def predict(self, dt):
+        o = self._oracle(self.pos, self.vel)
+        o.predict_positions(dt)
+        o.collision_detection(dt)
+        _, self.vel, self.pred, _ = o.download()
+
+    def partition(self):
+        cx = cell_x(self.pred[:, 0], self.spacing)
+        left, right = cx < self.x_lo, cx >= self.x_hi
+        stay = ~(left | right)
+        out = []
+        for m in (left, right):
+            out.append(self.to_backend(make_records(self.pos[m], self.vel[m], self.pred[m], self.ids[m], self.mass)))
+        self.ids, self.pos, self.vel, self.pred = self.ids[stay], self.pos[stay], self.vel[stay], self.pred[stay]
+        self.gid = [np.zeros(0, np.uint32), np.zeros(0, np.uint32)]
+        self.gcount = [0, 0]
+        return out[0], out[1]
+
+    def append_owned(self, rec):
+        rec = rec.numpy()
+        if not rec.shape[0]:
+            return
+        self.ids = np.concatenate([self.ids, record_ids(rec)])
+        self.pos = np.concatenate([self.pos, rec[:, 0:3]])
+        self.vel = np.concatenate([self.vel, rec[:, 4:7]])
+        self.pred = np.concatenate([self.pred, rec[:, 8:11]])
+
+    def pack_ghosts(self):
+        cx = cell_x(self.pred[:, 0], self.spacing)
+        out = []
+        for side, plane, open_end in ((0, self.x_lo, self.x_lo <= -(2 ** 31)), (1, self.x_hi - 1, self.x_hi >= 2 ** 31 - 1)):
+            m = (cx == plane) if not open_end else np.zeros(cx.shape, bool)
+            self.bids[side] = self.ids[m]
+            out.append(self.to_backend(make_records(self.pos[m], self.vel[m], self.pred[m], self.ids[m], self.mass)))
+        return out[0], out[1]
+
+    def append_ghosts(self, rec, side):
+        rec = rec.numpy()
+        self.grec[side] = rec
+        self.gid[side] = record_ids(rec)
+        self.gcount[side] = rec.shape[0]
+
+    def build(self):
+        g = np.concatenate(self.grec, axis=0) if (self.gcount[0] + self.gcount[1]) else np.zeros((0, REC), np.float32)
+        gids = np.concatenate(self.gid)
+        ids = np.concatenate([self.ids, gids])
+        pos = np.concatenate([self.pos, g[:, 0:3]])
+        vel = np.concatenate([self.vel, g[:, 4:7]])
+        pred = np.concatenate([self.pred, g[:, 8:11]])
+        order = np.argsort(ids, kind="stable")
+        self.l_ids = ids[order]
+        self.l_owned = (order < self.ids.shape[0])
+        self.o = self._oracle(pos[order], vel[order])
+        self.o.set_array("pred", pred[order])
+        self.o.spatial_search()
+
+    def _rows(self, ids):
+        return np.searchsorted(self.l_ids, ids)
+
+    def lambda_pass(self, dt):
+        self.o.compute_density()
+        self.o.compute_lambdas()
+
+    def delta_pass(self, dt):
+        self.o.compute_correction(dt)
+        self.o.update_predict_position()
+
+    def _halo_get(self, what):
+        if what == HALO_PRED_LAMBDA:
+            return np.concatenate([self.o.get_array("pred"), self.o.get_array("lambda")], axis=1)
+        name = {HALO_VELOCITY: "vel", HALO_OMEGA: "omega", HALO_POSITION: "pos"}[what]
+        a = self.o.get_array(name)
+        return np.concatenate([a, np.zeros((a.shape[0], 1), np.float32)], axis=1)
+
+    def halo_pack(self, what):
+        full = self._halo_get(what)
+        return tuple(self.to_backend(full[self._rows(self.bids[s])]) for s in (0, 1))
+
+    def halo_unpack(self, what, from_left, from_right):
+        for side, t in ((0, from_left), (1, from_right)):
+            t = t.numpy()
+            assert t.shape[0] == self.gcount[side]
+            if not t.shape[0]:
+                continue
+            rows = self._rows(self.gid[side])
+            if what == HALO_PRED_LAMBDA:
+                pred, lam = self.o.get_array("pred"), self.o.get_array("lambda")
+                pred[rows] = t[:, 0:3]
+                lam[rows, 0] = t[:, 3]
+                self.o.set_array("pred", pred)
+                self.o.set_array("lambda", lam)
+            else:
+                name = {HALO_VELOCITY: "vel", HALO_OMEGA: "omega", HALO_POSITION: "pos"}[what]
+                a = self.o.get_array(name)
+                a[rows] = t[:, 0:3]
+                self.o.set_array(name, a)
+
+    def finalize_stage(self, stage, dt):
+        if stage == 0:
+            self.o.update_velocity(dt)
+        elif stage == 1:
+            self.o.vorticity_omega()
+        elif stage == 2:
+            self.o.vorticity_apply(dt)
+        else:
+            self.o.xsph()
+        # owned state follows the oracle (ghost rows are dropped)
+        pos, vel, pred, _ = self.o.download()
+        m = self.l_owned
+        self.ids, self.pos, self.vel, self.pred = self.l_ids[m], pos[m], vel[m], pred[m]
+
+    def export(self):
+        return make_records(self.pos, self.vel, self.pred, self.ids, self.mass)
+
+    def sync(self):
+        pass

@@ -1,0 +1,93 @@
+"""CPU: the slab-decomposition protocol (fluidsimulation_amd/slab.py) on the oracle backend --
+in-process with 2-4 slabs and over torch.distributed gloo with world_size 2 -- must reproduce
+the single-domain oracle bit for bit (cell ids, neighbour order and therefore every sum agree)."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.slab_common import DT, build_local_group, single_domain_oracle, slab_scene
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def oracle_backend(p, cols, mass, lo, hi):
+    from oracle.slab_backend import OracleSlabBackend
+    return OracleSlabBackend(p, cols, mass, lo, hi)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_local_slabs_equal_single_domain(world):
+    p, pos, mass, cols, vel = slab_scene()
+    steps = 6
+    group, planes = build_local_group(oracle_backend, p, pos, mass, cols, vel, world)
+    start_owner = np.searchsorted(np.array(planes[1:-1]), np.floor(pos[:, 0] / np.float32(p.grid_spacing)), side="right")
+    for _ in range(steps):
+        group.step(DT)
+    ids, gpos, gvel = group.export()
+    opos, ovel = single_domain_oracle(p, pos, mass, cols, vel, steps)
+    assert np.array_equal(ids, np.arange(pos.shape[0]))
+    assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
+    # the test really migrated particles across slab planes
+    end_owner = np.searchsorted(np.array(planes[1:-1]), np.floor(opos[:, 0] / np.float32(p.grid_spacing)), side="right")
+    assert (start_owner != end_owner).sum() > 0
+
+
+def test_local_slabs_with_viscosity():
+    p, pos, mass, cols, vel = slab_scene(nx=16, iterations=2, xsph_c=0.01, vorticity_eps=0.05, vel_scale=2.0)
+    group, _ = build_local_group(oracle_backend, p, pos, mass, cols, vel, 3)
+    for _ in range(4):
+        group.step(DT)
+    ids, gpos, gvel = group.export()
+    opos, ovel = single_domain_oracle(p, pos, mass, cols, vel, 4)
+    assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gloo_worker(rank, world, port, steps, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    from fluidsimulation_amd.slab import SlabGroup, TorchExchange, populate, split_planes
+    from oracle.slab_backend import OracleSlabBackend
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p, pos, mass, cols, vel = slab_scene()
+    planes = split_planes(pos, p.grid_spacing, world)
+    b = OracleSlabBackend(p, cols, mass, planes[rank], planes[rank + 1])
+    populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
+             p.grid_spacing, vel=vel)
+    g = SlabGroup([b], TorchExchange(rank, world), int(p.solver_iterations))
+    for _ in range(steps):
+        g.step(DT)
+    ids, gpos, gvel = g.export()
+    np.savez(Path(out_dir) / f"rank{rank}.npz", ids=ids, pos=gpos, vel=gvel)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_equals_single_domain(tmp_path):
+    import torch.multiprocessing as mp
+    world, steps = 2, 5
+    port = _free_port()
+    mp.spawn(_gloo_worker, args=(world, port, steps, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    ids = np.concatenate([z["ids"] for z in parts])
+    order = np.argsort(ids)
+    gpos = np.concatenate([z["pos"] for z in parts])[order]
+    gvel = np.concatenate([z["vel"] for z in parts])[order]
+    p, pos, mass, cols, vel = slab_scene()
+    opos, ovel = single_domain_oracle(p, pos, mass, cols, vel, steps)
+    assert np.array_equal(ids[order], np.arange(pos.shape[0]))
+    assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
+    assert all(z["ids"].size > 0 for z in parts)

@@ -35,6 +35,24 @@ ALGO_BYTES = {
     "finalize": 48,
 }
 ALGO_BYTES_SUBSTEP_4IT = 382
+ALGO_BYTES_PER_ITER = 46           # 18 + 28
+
+
+def pmc_traffic(kernel_phase):
+    """HBM bytes per launch of the phase's kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_latest.json, written by tools/summarize_prof.py): FETCH_SIZE counts 64-B
+    requests at half their size for wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM;
+    calibrated on k_finalize: 32 MB read -> 16 MB counted), WRITE_SIZE is exact; both in KiB."""
+    f = ROOT / "profiles" / "pmc_latest.json"
+    names = {"lambda": "k_lambda<true, 0>", "delta": "k_delta<0>", "predict": "k_predict",
+             "finalize": "k_finalize", "neighbors": "k_neighbors"}
+    try:
+        d = json.loads(f.read_text())
+        k = d["kernels"][names[kernel_phase]]
+        return {"bytes_per_launch": (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0,
+                "particles_per_launch": d["particles_per_launch"], "source": str(f.relative_to(ROOT))}
+    except Exception:
+        return None
 
 
 def parse():
@@ -163,15 +181,21 @@ def main():
             dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
             per_launch_s = cand[dom]["ms_per_launch"] * 1e-3
             achieved = ALGO_BYTES[dom] * n_local / per_launch_s / 1e9
+            tr = pmc_traffic(dom)
+            traffic = None
+            if tr and tr["particles_per_launch"] == n_local:
+                traffic = tr["bytes_per_launch"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                        "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * n_local,
                         "algorithmic_bytes_per_particle": ALGO_BYTES[dom],
                         "avg_launch_ms": cand[dom]["ms_per_launch"], "particles_per_launch": n_local}
 
     if rank == 0:
         value = n_total * a.steps / elapsed
         cpu = None
-        if a.cpu_steps > 0:
+        if a.cpu_steps > 0 and world == 1:
             cb = tuple(a.cpu_block) if a.cpu_block else (min(block[0], 60), min(block[1], 60), min(block[2], 60))
             cpu = cpu_baseline(cb, a.iters, a.cpu_steps)
         out = {
@@ -190,7 +214,7 @@ def main():
             "config": {"workload": workload, "particles": n_total, "iterations": a.iters,
                        "arithmetic": "f32 state and accumulation, f64 SPH-kernel evaluation (as the reference CPU path)", "parallelism": parallelism,
                        "substeps_per_s": a.steps / elapsed},
-            "hbm_roofline_frac_substep": ALGO_BYTES_SUBSTEP_4IT * value / (HBM_PEAK_GBS * 1e9 * world),
+            "hbm_roofline_frac_substep": (290 - 2 * ALGO_BYTES_PER_ITER + a.iters * ALGO_BYTES_PER_ITER) * value / (HBM_PEAK_GBS * 1e9 * world),
             "roofline": roofline,
             "phases": phases,
             "cpu_baseline": cpu,

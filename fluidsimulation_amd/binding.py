@@ -172,6 +172,13 @@ def load_library(path: os.PathLike | None = None):
     if not p.exists():
         raise PbfError(PBF_ERR_NO_DEVICE,
                        f"HIP extension not built: {p} (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7 and loads it by path; libpbf_hip.so needs the
+    # same soname.  Whichever is loaded first serves both, and a process must end up with ONE
+    # HIP runtime (torch buffers are handed to the pbf_slab_* calls): let torch load first.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional for single-GPU use
+        pass
     lib = C.CDLL(str(p))
     vp = C.c_void_p
     lib.pbf_default_params.argtypes = [C.POINTER(PbfParams)]

@@ -26,7 +26,11 @@ def main():
     out = {}
     for k in agg:
         out[k] = {c: agg[k][c] / max(1, calls[k][c]) for c in agg[k]}   # per-launch averages
-    print(json.dumps(out, indent=1, sort_keys=True))
+    n = None
+    if "k_finalize" in out and "SQ_WAVES" in out["k_finalize"]:
+        n = int(round(out["k_finalize"]["SQ_WAVES"] * 64))   # one thread per particle, wave64
+    print(json.dumps({"particles_per_launch": n, "units": "per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB",
+                      "kernels": out}, indent=1, sort_keys=True))
 
 
 if __name__ == "__main__":

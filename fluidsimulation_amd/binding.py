@@ -153,7 +153,7 @@ SYMBOLS = [
     "pbf_profile_enable", "pbf_profile_reset", "pbf_profile_read", "pbf_num_phases",
     "pbf_phase_name", "pbf_solve_lambda", "pbf_solve_delta", "pbf_finalize_stage", "pbf_set_stream",
     "pbf_slab_set_bounds", "pbf_slab_partition", "pbf_slab_append", "pbf_slab_pack_ghosts",
-    "pbf_slab_pack_halo", "pbf_slab_unpack_halo", "pbf_slab_export",
+    "pbf_slab_pack_halo", "pbf_slab_unpack_halo", "pbf_slab_export", "pbf_selftest_sqrt",
 ]
 
 _lib = None
@@ -223,6 +223,7 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_slab_pack_halo.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.pbf_slab_unpack_halo.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_uint32]
     lib.pbf_slab_export.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.pbf_selftest_sqrt.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     if path is None:
         _lib = lib
     return lib
@@ -395,6 +396,11 @@ class PbfContext:
         k = C.c_uint32()
         self._ck(self.lib.pbf_slab_export(self._h, C.c_void_p(d_records), max_records, C.byref(k)))
         return int(k.value)
+
+    def selftest_sqrt(self):
+        bad, first = C.c_uint64(), C.c_uint32()
+        self._ck(self.lib.pbf_selftest_sqrt(self._h, C.byref(bad), C.byref(first)))
+        return int(bad.value), int(first.value)
 
     # -- device-time profile
     def profile_enable(self, on=True):

@@ -107,16 +107,31 @@ __device__ __forceinline__ float grad_scalar_strict(const KernConsts& k, float d
     return 0.0f;
 }
 
-// x^4 for x >= 0, correctly rounded (double-double square of a double-double square);
-// stands in for the reference's pow(x, 4) (Simulation.cpp:701), which glibc rounds
-// correctly in all but ~1e-5 of cases -- and the result is then cast to float.
-__device__ __forceinline__ double pow4_cr(double x) {
+// Correctly rounded fp32 square root (glm::distance -> sqrtf).  The compiler's expansion of
+// sqrtf costs ~17 instructions (input scaling for subnormals, v_sqrt_f32, two-sided fix-up);
+// for inputs >= 2^-96 one rsq and one Markstein-style fma correction give the same bits in 5
+// (verified EXHAUSTIVELY against sqrtf over every float in [2^-96, FLT_MAX] by
+// pbf_selftest_sqrt, tests/test_gpu_parity.py).  Zero, subnormal-range and non-finite inputs
+// take the library path.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    if (x >= 1.2621774e-29f && x <= 3.4028235e38f) {  // [2^-96, FLT_MAX]
+        float r = __builtin_amdgcn_rsqf(x);
+        float y = x * r;
+        float h = 0.5f * r;
+        float e = fmaf(-y, y, x);
+        y = fmaf(e, h, y);
+        return y;
+    }
+    return sqrtf(x);
+}
+
+// x^4 for a double that holds an fp32 value (the reference's pow(x, 4), Simulation.cpp:701,
+// where x = float / float): x*x has at most 48 significant bits and is exact in double, so
+// (x*x)*(x*x) rounds ONCE -- it is the correctly rounded x^4, which is what glibc's pow
+// returns in all but ~1e-5 of cases, and the result is cast to float afterwards.
+__device__ __forceinline__ double pow4_of_float(double x) {
     double a = x * x;
-    double ae = fma(x, x, -a);
-    double p = a * a;
-    double pe = fma(a, a, -p);
-    double t = (2.0 * a) * ae;
-    return p + (pe + t);
+    return a * a;
 }
 
 // ---- artificial pressure (Simulation.cpp:698-702), returns (float)scorr.
@@ -127,7 +142,7 @@ __device__ __forceinline__ double pow4_cr(double x) {
 // quotients ties can differ, but then x^4 underflows to 0 in the final float anyway.)
 __device__ __forceinline__ float scorr_strict(const KernConsts& k, float w) {
     float xf = (float)((double)w * k.inv_w_dq);
-    double x = pow4_cr((double)xf);
+    double x = pow4_of_float((double)xf);
     double s = k.scorr_k * x;
     s = s * k.dt_pow;
     return (float)s;

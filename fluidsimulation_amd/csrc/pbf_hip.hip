@@ -485,7 +485,7 @@ __global__ __launch_bounds__(BLOCK) void k_rest_density_terms(
     float dens = pi.w * kc.w_zero;
     for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, pos, [&](uint32_t, const float4& pj) {
         float ex = pj.x - pi.x, ey = pj.y - pi.y, ez = pj.z - pi.z;
-        float distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+        float distance = sqrt_rn(dot3(ex, ey, ez, ex, ey, ez));
         dens += pj.w * poly6_strict(kc, distance);
     });
     dens_by_id[id[i]] = dens;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __r
     for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, prd, [&](uint32_t j, const float4& xj) {
         float mj = UNIFORM_MASS ? uniform_mass : pos[j].w;
         float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-        float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        float distance = sqrt_rn(dot3(dx, dy, dz, dx, dy, dz));
         float w = poly6_strict(kc, distance);
         float gs = grad_scalar_strict<GRAD>(kc, distance);
         dens += mj * w;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
     float nx = xi.x, ny = xi.y, nz = xi.z;
     for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, prd, [&](uint32_t, const float4& xj) {
         float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-        float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        float distance = sqrt_rn(dot3(dx, dy, dz, dx, dy, dz));
         float sc = scorr_strict(kc, poly6_strict(kc, distance));
         float gs = grad_scalar_strict<GRAD>(kc, distance);
         // result = (1/rho0) * (lambda_i + lambda_j + (float)scorr) * gradW
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(const float4* __restrict__ 
     for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, pos, [&](uint32_t j, const float4& pj) {
         float4 vj = vel[j];
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        float distance = sqrt_rn(dot3(dx, dy, dz, dx, dy, dz));
         float gs = grad_scalar_strict<GRAD>(kc, distance);
         float gx = gs * dx, gy = gs * dy, gz = gs * dz;
         float ux = vj.x - vi.x, uy = vj.y - vi.y, uz = vj.z - vi.z;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity_apply(
     float ex = 0.f, ey = 0.f, ez = 0.f;
     for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, pos, [&](uint32_t j, const float4& pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        float distance = sqrt_rn(dot3(dx, dy, dz, dx, dy, dz));
         float gs = grad_scalar_strict<GRAD>(kc, distance);
         float s = (pj.w * inv_rho0) * omega[j].w;
         ex += s * (gs * dx);
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(BLOCK) void k_xsph(const float4* __restrict__ pos,
     for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, pos, [&](uint32_t j, const float4& pj) {
         float4 vj = vel[j];
         float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
-        float distance = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        float distance = sqrt_rn(dot3(dx, dy, dz, dx, dy, dz));
         float s = (pj.w * inv_rho0) * poly6_strict(kc, distance);
         ax += s * (vj.x - vi.x);
         ay += s * (vj.y - vi.y);
@@ -836,6 +836,23 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors_by_id(const uint32_t* __res
     counts[o] = cnt;
     for (uint32_t k = 0; k < cnt && k < stride; ++k)
         out[(size_t)o * stride + k] = id[nbr[(size_t)k * cap + i]];
+}
+
+// exhaustive check of sqrt_rn against the compiler's correctly rounded sqrtf
+__global__ __launch_bounds__(BLOCK) void k_selftest_sqrt(uint32_t first, uint32_t last,
+                                                         unsigned long long* __restrict__ bad,
+                                                         uint32_t* __restrict__ first_bad) {
+    unsigned long long local = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t b = (uint64_t)first + blockIdx.x * BLOCK + threadIdx.x; b <= last; b += stride) {
+        float x = __uint_as_float((uint32_t)b);
+        float a = sqrt_rn(x), r = sqrtf(x);
+        if (__float_as_uint(a) != __float_as_uint(r)) {
+            ++local;
+            atomicMin(first_bad, (uint32_t)b);
+        }
+    }
+    if (local) atomicAdd(bad, local);
 }
 
 struct StatPartial {
@@ -1931,6 +1948,24 @@ int pbf_profile_read(pbf_ctx* c, double* ms, uint64_t* calls, uint32_t max_phase
         if (ms) ms[i] = c->prof_ms[i];
         if (calls) calls[i] = c->prof_calls[i];
     }
+    return PBF_OK;
+}
+
+int pbf_selftest_sqrt(pbf_ctx* c, uint64_t* mismatches, uint32_t* first_bad) {
+    ENTER(c);
+    if (!mismatches || !first_bad) return fail(c, PBF_ERR_INVALID, "null output");
+    unsigned long long* d_bad = (unsigned long long*)c->staging;
+    uint32_t* d_first = (uint32_t*)((char*)c->staging + 8);
+    HIP_CK(c, hipMemsetAsync(d_bad, 0, 8, c->stream));
+    HIP_CK(c, hipMemsetAsync(d_first, 0xff, 4, c->stream));
+    // every non-negative float from the smallest subnormal to +inf (0x7f800000), plus zero
+    k_selftest_sqrt<<<4096, BLOCK, 0, c->stream>>>(0u, 0x7f800000u, d_bad, d_first);
+    LAUNCH_CK(c);
+    unsigned long long hb = 0;
+    HIP_CK(c, hipMemcpyAsync(&hb, d_bad, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipMemcpyAsync(first_bad, d_first, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    *mismatches = hb;
     return PBF_OK;
 }
 

@@ -231,6 +231,11 @@ int pbf_slab_unpack_halo(pbf_ctx* ctx, int32_t side, int32_t what, const void* d
 /* all owned particles as records, arbitrary order (synchronises) */
 int pbf_slab_export(pbf_ctx* ctx, void* d_records, uint32_t max_records, uint32_t* count);
 
+/* self-test (no reference counterpart): compares the kernels' 6-instruction correctly rounded
+ * fp32 square root with the compiler's sqrtf over EVERY non-negative float; *mismatches must
+ * be 0 (first_bad = bit pattern of the first differing input, 0xffffffff if none) */
+int pbf_selftest_sqrt(pbf_ctx* ctx, uint64_t* mismatches, uint32_t* first_bad);
+
 /* per-phase device time of the kernels launched by this ctx, measured with HIP events on
  * the ctx stream when enabled (replaces the ImGui chrono panel, Simulation.cpp:126-133).
  * phase names: pbf_phase_name(i), i < pbf_num_phases(). ms[i] accumulates, calls[i] counts. */

@@ -143,6 +143,14 @@ def test_density_lambda_correction_bit_exact():
     assert np.array_equal(gp, op) and np.array_equal(gv, ov)
 
 
+def test_fast_sqrt_is_correctly_rounded_exhaustively():
+    """sqrt_rn (csrc/pbf_device.h) == sqrtf for every non-negative float bit pattern"""
+    p, pos, mass, cols = scenes.c1_lattice(2, 2, 2)
+    g = PbfContext(p, device=0)
+    bad, first = g.selftest_sqrt()
+    assert bad == 0, f"{bad} mismatches, first at bit pattern {first:#x}"
+
+
 # ------------------------------------------------------------------ whole steps
 
 @pytest.mark.parametrize("dims", [(10, 100, 10), (4, 4, 4), (1, 1, 1)])

@@ -151,6 +151,8 @@ __device__ __forceinline__ float scorr_strict(const KernConsts& k, float w) {
 // Visit the neighbour row of particle i in order, with BATCH row entries and BATCH position
 // gathers in flight and the next batch of row entries prefetched behind them.  f(j, xj) is
 // called in row order (the summation order of the reference, Simulation.cpp:628,660,692).
+// Row loads stay predicated on k < cnt: loading them unconditionally (measured) costs more in
+// extra row traffic than the removed branches save.
 template <int BATCH, typename F>
 __device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t cnt,
                                                   const uint32_t* __restrict__ nbr, uint32_t cap,

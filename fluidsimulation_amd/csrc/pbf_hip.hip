@@ -289,17 +289,30 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wa
     return base + inc - v;
 }
 
+// loads SCAN_ITEMS consecutive counters of one thread as two 16-byte vectors when in range
+__device__ __forceinline__ void load_items(const uint32_t* __restrict__ a, uint32_t base,
+                                           uint32_t n, uint32_t (&c)[SCAN_ITEMS]) {
+    if (base + SCAN_ITEMS <= n) {
+        const uint4 lo = *reinterpret_cast<const uint4*>(a + base);
+        const uint4 hi = *reinterpret_cast<const uint4*>(a + base + 4);
+        c[0] = lo.x; c[1] = lo.y; c[2] = lo.z; c[3] = lo.w;
+        c[4] = hi.x; c[5] = hi.y; c[6] = hi.z; c[7] = hi.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) c[k] = (base + k < n) ? a[base + k] : 0u;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_scan_tile_sums(const uint32_t* __restrict__ count,
                                                           uint32_t ncell,
                                                           uint32_t* __restrict__ tile_sums) {
     __shared__ uint32_t lds_waves[BLOCK / 64];
     uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t c[SCAN_ITEMS];
+    load_items(count, base, ncell, c);
     uint32_t s = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        uint32_t c = base + k;
-        s += (c < ncell) ? count[c] : 0u;
-    }
+    for (int k = 0; k < SCAN_ITEMS; ++k) s += c[k];
     uint32_t total;
     block_excl_scan(s, lds_waves, total);
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
@@ -326,27 +339,41 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(uint32_t* __restrict__ cou
                                                       const uint32_t* __restrict__ tile_sums,
                                                       uint32_t* __restrict__ cell_start,
                                                       uint32_t* __restrict__ cursor) {
+    static_assert(SCAN_ITEMS == 8, "vector path below moves two uint4 per thread");
     __shared__ uint32_t lds_waves[BLOCK / 64];
     uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t c[SCAN_ITEMS];
+    load_items(count, base, ncell, c);
     uint32_t s = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        uint32_t idx = base + k;
-        c[k] = (idx < ncell) ? count[idx] : 0u;
-        s += c[k];
-    }
+    for (int k = 0; k < SCAN_ITEMS; ++k) s += c[k];
     uint32_t total;
     uint32_t ex = block_excl_scan(s, lds_waves, total) + tile_sums[blockIdx.x];
+    uint32_t e[SCAN_ITEMS];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        uint32_t idx = base + k;
-        if (idx < ncell) {
-            cell_start[idx] = ex;
-            cursor[idx] = ex;
-            count[idx] = 0u;
-        }
+        e[k] = ex;
         ex += c[k];
+    }
+    if (base + SCAN_ITEMS <= ncell) {
+        const uint4 lo = make_uint4(e[0], e[1], e[2], e[3]), hi = make_uint4(e[4], e[5], e[6], e[7]);
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(cell_start + base) = lo;
+        *reinterpret_cast<uint4*>(cell_start + base + 4) = hi;
+        *reinterpret_cast<uint4*>(cursor + base) = lo;
+        *reinterpret_cast<uint4*>(cursor + base + 4) = hi;
+        *reinterpret_cast<uint4*>(count + base) = z;
+        *reinterpret_cast<uint4*>(count + base + 4) = z;
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            uint32_t idx = base + k;
+            if (idx < ncell) {
+                cell_start[idx] = e[k];
+                cursor[idx] = e[k];
+                count[idx] = 0u;
+            }
+        }
     }
     // sentinel: cell_start[ncell] = n
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == BLOCK - 1) cell_start[ncell] = ex;

@@ -447,33 +447,44 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ 
     uint32_t* out = nbr + i;  // advances one row (cap entries) per accepted neighbour
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 pix = {xi.x, xi.x}, piy = {xi.y, xi.y}, piz = {xi.z, xi.z};
-    auto accept = [&](uint32_t ju) {
-        if (cnt < K) {
-            *out = ju;
-            out += cap;
-        }
-        ++cnt;
-    };
-    // candidate range [a,b): batches of 4 loads in flight, tested two at a time with packed
-    // fp32 math (each lane of a packed op rounds like the scalar op: still glm's dot order),
-    // accepted in order
+    // candidate range [a,b), in chunks of 32: first a branch-free test pass that records one
+    // accept bit per candidate (4 loads in flight, two candidates per packed fp32 op -- each
+    // half of a packed op rounds like the scalar op, so this is still glm's dot order), then an
+    // emit pass over the set bits in ascending order (the reference's cache order).
     auto sweep = [&](uint32_t a, uint32_t b) {
-        for (uint32_t j = a; j < b; j += 4) {
-            const uint32_t last = b - 1;
-            const uint32_t j1 = j + 1 < b ? j + 1 : last, j2 = j + 2 < b ? j + 2 : last,
-                           j3 = j + 3 < b ? j + 3 : last;
-            const float4 c0 = prd[j], c1 = prd[j1], c2 = prd[j2], c3 = prd[j3];
-            // glm::distance2(pi, pj) = dot(pj - pi, pj - pi)
-            f2 ex = (f2){c0.x, c1.x} - pix, ey = (f2){c0.y, c1.y} - piy, ez = (f2){c0.z, c1.z} - piz;
-            const f2 da = (ex * ex + ey * ey) + ez * ez;
-            ex = (f2){c2.x, c3.x} - pix;
-            ey = (f2){c2.y, c3.y} - piy;
-            ez = (f2){c2.z, c3.z} - piz;
-            const f2 db = (ex * ex + ey * ey) + ez * ez;
-            if (da.x <= square_h && j != i) accept(j);
-            if (da.y <= square_h && j + 1 < b && j + 1 != i) accept(j + 1);
-            if (db.x <= square_h && j + 2 < b && j + 2 != i) accept(j + 2);
-            if (db.y <= square_h && j + 3 < b && j + 3 != i) accept(j + 3);
+        for (uint32_t s = a; s < b; s += 32) {
+            const uint32_t len = b - s < 32u ? b - s : 32u;
+            const uint32_t last = s + len - 1;
+            uint32_t mask = 0;
+            for (uint32_t u = 0; u < len; u += 4) {
+                const uint32_t j = s + u;
+                const uint32_t j1 = j + 1 < last ? j + 1 : last, j2 = j + 2 < last ? j + 2 : last,
+                               j3 = j + 3 < last ? j + 3 : last;
+                const float4 c0 = prd[j], c1 = prd[j1], c2 = prd[j2], c3 = prd[j3];
+                // glm::distance2(pi, pj) = dot(pj - pi, pj - pi)
+                f2 ex = (f2){c0.x, c1.x} - pix, ey = (f2){c0.y, c1.y} - piy, ez = (f2){c0.z, c1.z} - piz;
+                const f2 da = (ex * ex + ey * ey) + ez * ez;
+                ex = (f2){c2.x, c3.x} - pix;
+                ey = (f2){c2.y, c3.y} - piy;
+                ez = (f2){c2.z, c3.z} - piz;
+                const f2 db = (ex * ex + ey * ey) + ez * ez;
+                const uint32_t nib = (da.x <= square_h ? 1u : 0u) | (da.y <= square_h ? 2u : 0u) |
+                                     (db.x <= square_h ? 4u : 0u) | (db.y <= square_h ? 8u : 0u);
+                mask |= nib << u;
+            }
+            // drop the clamped tail duplicates and the particle itself (p_j == i, :216)
+            if (len < 32u) mask &= (1u << len) - 1u;
+            const uint32_t self = i - s;  // wraps to a huge value when i < s
+            if (self < 32u) mask &= ~(1u << self);
+            while (mask) {
+                const uint32_t k = (uint32_t)__builtin_ctz(mask);
+                mask &= mask - 1u;
+                if (cnt < K) {
+                    *out = s + k;
+                    out += cap;
+                }
+                ++cnt;
+            }
         }
     };
     for (int dx = -1; dx <= 1; ++dx) {

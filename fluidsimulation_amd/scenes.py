@@ -120,3 +120,46 @@ def fluid_cube_reference():
     y = F(0.75) + d * j.astype(F)
     z = F(0.0) + d * k.astype(F)
     return np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(F), float(mass)
+
+
+def boundary_particles_reference():
+    """Simulation::InitializeBoundaryParticles (Simulation.cpp:356-490) exactly: one-layer particle
+    walls -- floor 80x80 at y = 0, left/right walls one diameter outside the floor's x extent,
+    back/front walls one diameter outside the side walls' z extent -- 32 000 particles.  The
+    reference's CPU step never reads them (only its CUDA kernels do), so the solver does not
+    either; the generator exists so the scene data of row a5 is reproducible."""
+    _h, r, _v, mass, _rho = sim_params_constants()
+    d = F(F(2.0) * r)
+    thickness = 1
+    out = []
+    # bottom: half_extend1 = (1, d*thickness, 1)
+    nx, nz = int(F(1.0) / d), int(F(1.0) / d)
+    i, k = np.meshgrid(np.arange(-nx, nx), np.arange(-nz, nz), indexing="ij")
+    x = F(0.0) + d * i.astype(F)
+    z = F(0.0) + d * k.astype(F)
+    y = np.full_like(x, F(0.0) - d * F(0))
+    out.append(np.stack([x, y, z], -1).reshape(-1, 3))
+    left_margin = F(x.min() - d)
+    right_margin = F(x.max() + d)
+    # left & right: half_extend2 = (d*thickness, 1, 1); origins (margin, ny*d, 0); interleaved
+    ny, nz = int(F(1.0) / d), int(F(1.0) / d)
+    j, k = np.meshgrid(np.arange(-ny, ny), np.arange(-nz, nz), indexing="ij")
+    yy = d * j.astype(F) + F(F(ny) * d)
+    zz = d * k.astype(F) + F(0.0)
+    xl = np.full_like(yy, F(d * F(0)) + left_margin)
+    xr = np.full_like(yy, F(d * F(0)) + right_margin)
+    lr = np.stack([np.stack([xl, yy, zz], -1), np.stack([xr, yy, zz], -1)], axis=2)  # left, right, ...
+    out.append(lr.reshape(-1, 3))
+    back_margin = F(zz.min() - d)
+    front_margin = F(zz.max() + d)
+    # back & front: half_extend3 = (1, 1, d*thickness); origins (0, ny*d, margin); interleaved
+    nx, ny = int(F(1.0) / d), int(F(1.0) / d)
+    i, j = np.meshgrid(np.arange(-nx, nx), np.arange(-ny, ny), indexing="ij")
+    xx = d * i.astype(F) + F(0.0)
+    yy = d * j.astype(F) + F(F(ny) * d)
+    zb = np.full_like(xx, F(d * F(0)) + back_margin)
+    zf = np.full_like(xx, F(d * F(0)) + front_margin)
+    bf = np.stack([np.stack([xx, yy, zb], -1), np.stack([xx, yy, zf], -1)], axis=2)
+    out.append(bf.reshape(-1, 3))
+    assert thickness == 1
+    return np.concatenate(out, axis=0).astype(F), float(mass)

@@ -325,3 +325,35 @@ def test_hip_reproduces_golden(name):
     pos, vel, _ = g.download()
     assert np.array_equal(pos, z["pos"]) and np.array_equal(vel, z["vel"])
     assert np.float32(g.rest_density()) == z["rest_density"]
+
+
+# ------------------------------------------------------------------ BASELINE full size (C3)
+
+def test_c3_1m_particles_two_steps_and_structure():
+    """C3 at full size (100^3 = 1 000 000 particles, 4 iterations): cell order, neighbour
+    symmetry and the state after two sub-steps, against the oracle on the same inputs."""
+    p, pos, mass, cols = scenes.c3_block()
+    g, o = make_pair(p, pos, mass, cols)
+    g.predict(DT); g.build_grid()
+    xyz, key, sid, start = g.cells()
+    # sortedness: keys ascend along the sorted order, ids ascend inside a cell
+    ks = key[sid]
+    assert np.all(np.diff(ks.astype(np.int64)) >= 0)
+    same = ks[1:] == ks[:-1]
+    assert np.all(sid[1:][same] > sid[:-1][same])
+    assert start[-1] == pos.shape[0]
+    # neighbour relation is symmetric: every (i, j) has its (j, i)
+    cnt, nb = g.neighbors()
+    i_idx = np.repeat(np.arange(pos.shape[0], dtype=np.int64), cnt)
+    j_idx = nb[np.arange(nb.shape[1])[None, :] < cnt[:, None]].astype(np.int64)
+    fwd = np.sort(i_idx * pos.shape[0] + j_idx)
+    bwd = np.sort(j_idx * pos.shape[0] + i_idx)
+    assert np.array_equal(fwd, bwd)
+    # finish this sub-step and run one more; compare with the oracle
+    g.solve(DT); g.finalize(DT)
+    g.step(DT)
+    g.sync()
+    o.step(DT); o.step(DT)
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)

@@ -68,6 +68,18 @@ def test_setup_sim_params_constants(lib):
     assert pos[0].tolist() == [np.float32(-20) * np.float32(2 * sr), np.float32(0.75) + np.float32(-20) * np.float32(2 * sr), np.float32(-20) * np.float32(2 * sr)]
 
 
+def test_boundary_particle_generator_counts():
+    # Simulation.cpp:356-490 -> N_b = 32 000: 80x80 floor + 4 walls of 80x80
+    pos, _ = scenes.boundary_particles_reference()
+    assert pos.shape == (32000, 3)
+    d = np.float32(2) * scenes.sim_params_constants()[1]
+    floor = pos[:6400]
+    assert np.all(floor[:, 1] == 0) and floor[:, 0].min() == np.float32(-40) * d
+    walls = pos[6400:]
+    assert walls[:, 1].min() == 0 and abs(walls[:, 1].max() - np.float32(79) * d) < 1e-6
+    assert np.unique(pos, axis=0).shape[0] == 32000
+
+
 def test_hash_and_flooring_kats(lib):
     # NeighborSearch.cpp:255-266
     assert lib.orc_hash_value(1, 2, 3) == (73856093 + 2 * 19349663 + 3 * 83492791) % 2 ** 32

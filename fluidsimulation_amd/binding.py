@@ -41,6 +41,7 @@ class PbfParams(C.Structure):
         ("capacity", C.c_uint32),
         ("max_neighbors", C.c_uint32),
         ("grid_dim", C.c_int32 * 3),
+        ("grid_origin_cell", C.c_int32 * 3),
         ("grid_spacing", C.c_float),
         ("effective_radius", C.c_float),
         ("gravity", C.c_float * 3),

@@ -31,6 +31,7 @@ struct KernConsts {
 
 struct GridConsts {
     int32_t gx, gy, gz;
+    int32_t ox, oy, oz;  // Flooring cell that maps to grid index (0,0,0)
     float spacing;
 };
 
@@ -71,8 +72,9 @@ __device__ __forceinline__ int32_t wrap(int32_t c, int32_t g) {
 }
 
 __device__ __forceinline__ uint32_t cell_key(const GridConsts& G, int32_t cx, int32_t cy, int32_t cz) {
-    return ((uint32_t)wrap(cx, G.gx) * (uint32_t)G.gy + (uint32_t)wrap(cy, G.gy)) * (uint32_t)G.gz +
-           (uint32_t)wrap(cz, G.gz);
+    return ((uint32_t)wrap(cx - G.ox, G.gx) * (uint32_t)G.gy + (uint32_t)wrap(cy - G.oy, G.gy)) *
+               (uint32_t)G.gz +
+           (uint32_t)wrap(cz - G.oz, G.gz);
 }
 
 // ---- STRICT: SPHKernel::Poly6_W (SPHKernel.h:9-30)

@@ -428,19 +428,18 @@ __global__ __launch_bounds__(BLOCK) void k_reorder(
 // x outermost, z innermost, bucket order inside a cell, j != i, dist2 <= h*h (inclusive).
 // Cells are z-fastest in the key, so the visiting order equals the reference's.
 
-__global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ prd,
+__device__ __forceinline__ void neighbors_global_path(uint32_t i, const float4* __restrict__ prd,
                                                      const uint32_t* __restrict__ cell_start,
                                                      uint32_t n, uint32_t cap, uint32_t K,
                                                      GridConsts G, float square_h,
                                                      uint32_t* __restrict__ nbr,
                                                      uint32_t* __restrict__ nbr_count,
                                                      DevFlags* __restrict__ flags) {
-    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float4 xi = prd[i];
     const int32_t cx = floor_cell(xi.x, G.spacing), cy = floor_cell(xi.y, G.spacing),
                   cz = floor_cell(xi.z, G.spacing);
-    const uint32_t wz = (uint32_t)wrap(cz, G.gz);
+    const uint32_t wz = (uint32_t)wrap(cz - G.oz, G.gz);
     // the three z-cells of one (dx,dy) are consecutive keys unless the z index wraps
     const bool zrun = wz >= 1u && wz + 1u < (uint32_t)G.gz;
     uint32_t cnt = 0;
@@ -488,15 +487,15 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ 
         }
     };
     for (int dx = -1; dx <= 1; ++dx) {
-        const uint32_t wx = (uint32_t)wrap(cx + dx, G.gx);
+        const uint32_t wx = (uint32_t)wrap(cx + dx - G.ox, G.gx);
         for (int dy = -1; dy <= 1; ++dy) {
-            const uint32_t wy = (uint32_t)wrap(cy + dy, G.gy);
+            const uint32_t wy = (uint32_t)wrap(cy + dy - G.oy, G.gy);
             const uint32_t row = (wx * (uint32_t)G.gy + wy) * (uint32_t)G.gz;
             if (zrun) {
                 sweep(cell_start[row + wz - 1u], cell_start[row + wz + 2u]);
             } else {
                 for (int dz = -1; dz <= 1; ++dz) {
-                    const uint32_t k = row + (uint32_t)wrap(cz + dz, G.gz);
+                    const uint32_t k = row + (uint32_t)wrap(cz + dz - G.oz, G.gz);
                     sweep(cell_start[k], cell_start[k + 1]);
                 }
             }
@@ -504,6 +503,156 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ 
     }
     nbr_count[i] = cnt < K ? cnt : K;
     if (cnt > K) {  // rare: keep the per-particle atomics off the common path
+        atomicAdd(&flags->neighbor_overflow, 1u);
+        atomicMax(&flags->max_count, cnt);
+    }
+}
+
+
+// LDS-staged form of the same sweep.  A workgroup owns 256 consecutive sorted particles, i.e.
+// a run of ~54 consecutive cells of one or two z-columns.  For each of the nine (dx,dy)
+// columns the candidates of ALL its particles form ONE contiguous slot range
+// [cell_start[kf+off-1], cell_start[kl+off+2]) (kf/kl = first/last key of the workgroup), so
+// the workgroup stages nine coalesced ranges (~2400 positions) into LDS as SoA x[], y[], z[]
+// once, and every thread then reads its candidates four at a time with ds_read_b128 -- the four
+// x (y, z) of consecutive candidates arrive already packed for v_pk_* math, with no global
+// load and no address arithmetic in the inner loop.  Visiting order and arithmetic are those
+// of neighbors_global_path (which remains the path for workgroups that touch a grid edge,
+// where keys wrap, or whose ranges exceed the LDS budget).
+constexpr uint32_t NB_LDS_T = 3072;   // staged candidates per workgroup (36 KB as SoA fp32)
+
+__global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ prd,
+                                                     const uint32_t* __restrict__ cell_start,
+                                                     uint32_t n, uint32_t cap, uint32_t K,
+                                                     GridConsts G, float square_h,
+                                                     uint32_t* __restrict__ nbr,
+                                                     uint32_t* __restrict__ nbr_count,
+                                                     DevFlags* __restrict__ flags) {
+    __shared__ __align__(16) float sx[NB_LDS_T + 32];
+    __shared__ __align__(16) float sy[NB_LDS_T + 32];
+    __shared__ __align__(16) float sz[NB_LDS_T + 32];
+    __shared__ uint32_t sA[9], sBase[10], sKey[2];
+    __shared__ int sOk;
+
+    const uint32_t i0 = xcd_block(blockIdx.x, gridDim.x) * BLOCK;
+    const uint32_t i = i0 + threadIdx.x;
+    const bool active = i < n;
+    const uint32_t ilast = (i0 + BLOCK <= n ? i0 + BLOCK : n) - 1;
+
+    float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t key = 0;
+    bool interior = true;
+    if (active) {
+        xi = prd[i];
+        const uint32_t wx = (uint32_t)wrap(floor_cell(xi.x, G.spacing) - G.ox, G.gx);
+        const uint32_t wy = (uint32_t)wrap(floor_cell(xi.y, G.spacing) - G.oy, G.gy);
+        const uint32_t wz = (uint32_t)wrap(floor_cell(xi.z, G.spacing) - G.oz, G.gz);
+        key = (wx * (uint32_t)G.gy + wy) * (uint32_t)G.gz + wz;
+        interior = wx >= 1u && wx + 1u < (uint32_t)G.gx && wy >= 1u && wy + 1u < (uint32_t)G.gy &&
+                   wz >= 1u && wz + 1u < (uint32_t)G.gz;
+        if (i == i0) sKey[0] = key;
+        if (i == ilast) sKey[1] = key;
+    }
+    if (threadIdx.x == 0) sOk = 1;
+    __syncthreads();
+    bool lds_path = true;
+    {
+        if (threadIdx.x < 9) {
+            // key window of the workgroup shifted to column (dx,dy), clamped to the grid: every
+            // interior particle's three cells lie inside it (edge particles take the global path)
+            const int dx = (int)threadIdx.x / 3 - 1, dy = (int)threadIdx.x % 3 - 1;
+            const int32_t off = (dx * G.gy + dy) * G.gz;
+            const int32_t ncell = G.gx * G.gy * G.gz;
+            int32_t lo = (int32_t)sKey[0] + off - 1, hi = (int32_t)sKey[1] + off + 2;
+            lo = lo < 0 ? 0 : (lo > ncell ? ncell : lo);
+            hi = hi < lo ? lo : (hi > ncell ? ncell : hi);
+            const uint32_t A = cell_start[lo];
+            const uint32_t B = cell_start[hi];
+            sA[threadIdx.x] = A;
+            sBase[threadIdx.x + 1] = B - A;   // length for now
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0;
+            sBase[0] = 0;
+            for (int r = 0; r < 9; ++r) {
+                const uint32_t len = sBase[r + 1];
+                sBase[r] = acc;
+                acc += len;
+            }
+            sBase[9] = acc;
+            if (acc > NB_LDS_T) sOk = 0;
+        }
+        __syncthreads();
+        lds_path = sOk != 0;
+    }
+    if (!lds_path) {
+        neighbors_global_path(i, prd, cell_start, n, cap, K, G, square_h, nbr, nbr_count, flags);
+        return;
+    }
+    // stage the nine ranges, coalesced
+    for (int r = 0; r < 9; ++r) {
+        const uint32_t A = sA[r], base = sBase[r], len = sBase[r + 1] - base;
+        for (uint32_t m = threadIdx.x; m < len; m += BLOCK) {
+            const float4 v = prd[A + m];
+            sx[base + m] = v.x;
+            sy[base + m] = v.y;
+            sz[base + m] = v.z;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    if (!interior) {  // grid-edge cell: its neighbour keys wrap, the staged window does not apply
+        neighbors_global_path(i, prd, cell_start, n, cap, K, G, square_h, nbr, nbr_count, flags);
+        return;
+    }
+
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 pix = {xi.x, xi.x, xi.x, xi.x}, piy = {xi.y, xi.y, xi.y, xi.y},
+             piz = {xi.z, xi.z, xi.z, xi.z};
+    uint32_t cnt = 0;
+    uint32_t* out = nbr + i;
+    for (int r = 0; r < 9; ++r) {   // r = (dx+1)*3 + (dy+1): x outermost, then y; z inside the run
+        const int dx = r / 3 - 1, dy = r % 3 - 1;
+        const int32_t off = (dx * G.gy + dy) * G.gz;
+        const uint32_t a = cell_start[(uint32_t)((int32_t)key + off - 1)];
+        const uint32_t b = cell_start[(uint32_t)((int32_t)key + off + 2)];
+        const uint32_t A = sA[r], base = sBase[r];
+        const uint32_t la = base + (a - A), lb = base + (b - A);   // LDS index range
+        const uint32_t to_slot = A - base;                          // LDS index -> sorted slot
+        const uint32_t lself = base + (i - A);                      // only meaningful for r == 4
+        for (uint32_t s = la & ~3u; s < lb; s += 32) {
+            uint32_t mask = 0;
+            for (uint32_t u = 0; u < 32u && s + u < lb; u += 4) {
+                const f4 cx4 = *reinterpret_cast<const f4*>(&sx[s + u]);
+                const f4 cy4 = *reinterpret_cast<const f4*>(&sy[s + u]);
+                const f4 cz4 = *reinterpret_cast<const f4*>(&sz[s + u]);
+                // glm::distance2(pi, pj) = dot(pj - pi, pj - pi), four candidates per op
+                const f4 ex = cx4 - pix, ey = cy4 - piy, ez = cz4 - piz;
+                const f4 d2 = (ex * ex + ey * ey) + ez * ez;
+                const uint32_t nib = (d2.x <= square_h ? 1u : 0u) | (d2.y <= square_h ? 2u : 0u) |
+                                     (d2.z <= square_h ? 4u : 0u) | (d2.w <= square_h ? 8u : 0u);
+                mask |= nib << u;
+            }
+            if (s < la) mask &= ~((1u << (la - s)) - 1u);           // entries before the range
+            if (lb - s < 32u) mask &= (1u << (lb - s)) - 1u;        // entries after it
+            if (r == 4) {                                            // the particle itself (:216)
+                const uint32_t self = lself - s;
+                if (self < 32u) mask &= ~(1u << self);
+            }
+            while (mask) {
+                const uint32_t k = (uint32_t)__builtin_ctz(mask);
+                mask &= mask - 1u;
+                if (cnt < K) {
+                    *out = s + k + to_slot;
+                    out += cap;
+                }
+                ++cnt;
+            }
+        }
+    }
+    nbr_count[i] = cnt < K ? cnt : K;
+    if (cnt > K) {
         atomicAdd(&flags->neighbor_overflow, 1u);
         atomicMax(&flags->max_count, cnt);
     }
@@ -1080,6 +1229,9 @@ GridConsts make_grid(const pbf_params& P) {
     g.gx = P.grid_dim[0];
     g.gy = P.grid_dim[1];
     g.gz = P.grid_dim[2];
+    g.ox = P.grid_origin_cell[0];
+    g.oy = P.grid_origin_cell[1];
+    g.oz = P.grid_origin_cell[2];
     g.spacing = P.grid_spacing;
     return g;
 }

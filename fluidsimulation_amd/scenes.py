@@ -85,6 +85,10 @@ def dam_break(nx, ny, nz, iterations=4, tank_x_factor=2.5, xsph_c=0.0, vorticity
     ext = (hi - lo) / h
     p.grid_dim[:] = [_grid_dim_for(int(ext[0])), _grid_dim_for(int(min(ext[1], 2.0 * ny * d / h))),
                      _grid_dim_for(int(ext[2]))]
+    # one spare cell below the tank on every axis: no fluid cell sits on a grid face, where
+    # neighbour keys wrap and the neighbour build leaves its LDS-staged path
+    c0 = np.floor(lo / h).astype(int)
+    p.grid_origin_cell[:] = [int(c0[0]) - 1, int(c0[1]) - 1, int(c0[2]) - 1]
     p.epsilon = 100.0                 # SimParams.epsilon, Simulation.cpp:337
     p.scorr_dt_power = 3              # cuda_simulation.cu:973
     p.rest_density_mode = PBF_RHO0_FIXED

@@ -84,6 +84,9 @@ typedef struct pbf_params {
     uint32_t capacity;          /* max particles this ctx can hold (owned + ghosts)        */
     uint32_t max_neighbors;     /* rows of the neighbour table (m_search_cache bound)      */
     int32_t  grid_dim[3];       /* wrap-around cell grid; 64^3 at Simulation.cpp:46        */
+    int32_t  grid_origin_cell[3]; /* Flooring cell that maps to grid index (0,0,0); the CUDA
+                                   path's world_origin (Simulation.cpp:340) in cell units.
+                                   Only the internal key depends on it, never the results  */
     float    grid_spacing;      /* m_grid_spacing = 1.f, NeighborSearch.cpp:17             */
     float    effective_radius;  /* h; effective_radius = 1.f, Simulation.cpp:88            */
     float    gravity[3];        /* (0, m_world_desc.gravity, 0), Simulation.cpp:16,592     */

@@ -36,7 +36,7 @@ constexpr int BLOCK = 256;
 constexpr int SWEEP_BATCH = 4;                    // neighbour-row entries / gathers in flight
 constexpr int SCAN_ITEMS = 8;                     // items per thread in the scan tiles
 constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;     // 2048 cells per workgroup
-constexpr uint32_t MAX_SCAN_BLOCKS = 8192;        // second level handled by one workgroup
+constexpr uint32_t MAX_SCAN_BLOCKS = 131072;      // second level: one workgroup loops over the tile sums
 constexpr float REF_PI = 3.1415926f;              // reference common.h:8
 
 enum Phase {
@@ -1294,7 +1294,7 @@ int validate_params(const pbf_params& P, std::string& why) {
     for (int a = 0; a < 3; ++a)
         if (P.grid_dim[a] < 3 || P.grid_dim[a] > 4096) { why = "grid_dim must be in [3, 4096]"; return PBF_ERR_INVALID; }
     uint64_t ncell = (uint64_t)P.grid_dim[0] * P.grid_dim[1] * P.grid_dim[2];
-    if (ncell > (uint64_t)MAX_SCAN_BLOCKS * SCAN_TILE) { why = "grid has too many cells (max 16777216)"; return PBF_ERR_INVALID; }
+    if (ncell > (uint64_t)MAX_SCAN_BLOCKS * SCAN_TILE) { why = "grid has too many cells (max 268435456)"; return PBF_ERR_INVALID; }
     if (!(P.grid_spacing > 0.f) || !(P.effective_radius > 0.f)) { why = "grid_spacing and effective_radius must be > 0"; return PBF_ERR_INVALID; }
     if (P.effective_radius > P.grid_spacing) { why = "effective_radius must not exceed grid_spacing (27-cell sweep)"; return PBF_ERR_INVALID; }
     if (P.solver_iterations < 0 || P.scorr_dt_power < 0 || P.scorr_dt_power > 8) { why = "bad iteration / scorr_dt_power"; return PBF_ERR_INVALID; }

@@ -322,6 +322,31 @@ def populate(backend, pos, mass, ids, planes_lo, planes_hi, spacing, vel=None):
     return int(m.sum())
 
 
+def rank_local_params(params: PbfParams, pos, planes, rank, world, headroom=1.5):
+    """This rank's pbf_params: capacity for its share (+ headroom for drift and ghosts) and a
+    rank-local cell grid that only spans the slab's x range (+ ghost planes and a migration
+    margin).  The wrap-around key makes the x extent of the global scene irrelevant to a rank,
+    so the per-step scan cost follows the slab, not the scene."""
+    p = params.copy()
+    share = int(np.ceil(pos.shape[0] / world))
+    p.capacity = int(share * headroom) + 65536
+    cx = cell_x(pos[:, 0], params.grid_spacing)
+    if params.container_enabled:
+        x_min = int(np.floor(params.container_min[0] / params.grid_spacing))
+        x_max = int(np.floor(min(params.container_max[0], 1e30) / params.grid_spacing))
+    else:
+        x_min, x_max = int(cx.min()), int(cx.max())
+    lo = max(planes[rank], x_min) if planes[rank] != INT32_MIN else x_min
+    hi = min(planes[rank + 1], x_max + 1) if planes[rank + 1] != INT32_MAX else x_max + 1
+    width = max(hi - lo, 1) + 8
+    gx = 16
+    while gx < width:
+        gx *= 2
+    p.grid_dim[0] = min(gx, int(params.grid_dim[0]))
+    p.grid_origin_cell[0] = lo - 4
+    return p
+
+
 class SlabSimulation:
     """What bench.py and multi-GPU callers use: this rank's slab of a scene, over RCCL."""
 
@@ -330,9 +355,7 @@ class SlabSimulation:
         import torch.distributed as dist
         planes = split_planes(pos, params.grid_spacing, world)
         self.planes = planes
-        p = params.copy()
-        share = int(np.ceil(pos.shape[0] / world))
-        p.capacity = int(share * headroom) + 65536
+        p = rank_local_params(params, pos, planes, rank, world, headroom)
         self.backend = HipSlabBackend(p, colliders, mass, planes[rank], planes[rank + 1], device=device)
         ids = np.arange(pos.shape[0], dtype=np.uint32)
         self.n_initial = populate(self.backend, pos, mass, ids, planes[rank], planes[rank + 1],

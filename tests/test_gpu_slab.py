@@ -65,6 +65,29 @@ def test_hip_slabs_larger_block_vs_single_gpu_ctx():
     assert np.array_equal(gpos, spos) and np.array_equal(gvel, svel)
 
 
+def test_rank_local_grids_do_not_change_results():
+    """every slab on its own narrow wrap-around grid (what bench.py --gpus N runs)"""
+    from fluidsimulation_amd.slab import (LocalExchange, SlabGroup, populate, rank_local_params,
+                                          split_planes)
+    p, pos, mass, cols, vel = slab_scene(nx=48, ny=8, nz=8, iterations=3, vel_scale=3.0)
+    world, steps = 4, 5
+    planes = split_planes(pos, p.grid_spacing, world)
+    ids = np.arange(pos.shape[0], dtype=np.uint32)
+    backends = []
+    for r in range(world):
+        q = rank_local_params(p, pos, planes, r, world)
+        assert int(q.grid_dim[0]) < int(p.grid_dim[0])
+        b = hip_backend(q, cols, mass, planes[r], planes[r + 1])
+        populate(b, pos, mass, ids, planes[r], planes[r + 1], p.grid_spacing, vel=vel)
+        backends.append(b)
+    group = SlabGroup(backends, LocalExchange(world), int(p.solver_iterations))
+    for _ in range(steps):
+        group.step(DT)
+    _, gpos, gvel = group.export()
+    opos, ovel = single_domain_oracle(p, pos, mass, cols, vel, steps)
+    assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
+
+
 def test_id_indexed_readback_is_refused_in_slab_mode():
     from fluidsimulation_amd import PbfError
     p, pos, mass, cols, vel = slab_scene()
@@ -85,11 +108,13 @@ def _worker(rank, world, port, steps, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, str(ROOT))
     import torch.distributed as dist
-    from fluidsimulation_amd.slab import SlabGroup, TorchExchange, populate, split_planes
+    from fluidsimulation_amd.slab import (SlabGroup, TorchExchange, populate, rank_local_params,
+                                          split_planes)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     p, pos, mass, cols, vel = slab_scene()
     planes = split_planes(pos, p.grid_spacing, world)
-    b = hip_backend(p, cols, mass, planes[rank], planes[rank + 1])
+    # the rank-local grid SlabSimulation (bench.py --gpus N) uses
+    b = hip_backend(rank_local_params(p, pos, planes, rank, world), cols, mass, planes[rank], planes[rank + 1])
     populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
              p.grid_spacing, vel=vel)
     g = SlabGroup([b], TorchExchange(rank, world), int(p.solver_iterations))

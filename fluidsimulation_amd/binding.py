@@ -153,7 +153,8 @@ SYMBOLS = [
     "pbf_get_neighbors", "pbf_get_stats", "pbf_get_rest_density", "pbf_num_particles",
     "pbf_profile_enable", "pbf_profile_reset", "pbf_profile_read", "pbf_num_phases",
     "pbf_phase_name", "pbf_solve_lambda", "pbf_solve_delta", "pbf_finalize_stage", "pbf_set_stream",
-    "pbf_slab_set_bounds", "pbf_slab_partition", "pbf_slab_append", "pbf_slab_pack_ghosts",
+    "pbf_slab_set_bounds", "pbf_slab_split", "pbf_slab_split_done", "pbf_slab_append_owned",
+    "pbf_slab_append_ghosts",
     "pbf_slab_pack_halo", "pbf_slab_unpack_halo", "pbf_slab_export", "pbf_selftest_sqrt",
 ]
 
@@ -217,12 +218,13 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_solve_delta.argtypes = [vp, C.c_float]
     lib.pbf_finalize_stage.argtypes = [vp, C.c_int32, C.c_float]
     lib.pbf_set_stream.argtypes = [vp, vp]
-    lib.pbf_slab_set_bounds.argtypes = [vp, C.c_int32, C.c_int32]
-    lib.pbf_slab_partition.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32 * 3)]
-    lib.pbf_slab_append.argtypes = [vp, vp, C.c_uint32, C.c_int32]
-    lib.pbf_slab_pack_ghosts.argtypes = [vp, C.c_int32, vp, C.c_uint32, C.POINTER(C.c_uint32)]
-    lib.pbf_slab_pack_halo.argtypes = [vp, C.c_int32, C.c_int32, vp]
-    lib.pbf_slab_unpack_halo.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_uint32]
+    lib.pbf_slab_set_bounds.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    lib.pbf_slab_split.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp]
+    lib.pbf_slab_split_done.argtypes = [vp, C.POINTER(C.c_uint32 * 6)]
+    lib.pbf_slab_append_owned.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
+    lib.pbf_slab_append_ghosts.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
+    lib.pbf_slab_pack_halo.argtypes = [vp, C.c_int32, vp, vp]
+    lib.pbf_slab_unpack_halo.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp, C.c_uint32]
     lib.pbf_slab_export.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.pbf_selftest_sqrt.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     if path is None:
@@ -368,30 +370,37 @@ class PbfContext:
     def set_stream(self, stream_handle: int):
         self._ck(self.lib.pbf_set_stream(self._h, C.c_void_p(stream_handle)))
 
-    def slab_set_bounds(self, x_lo: int, x_hi: int):
-        self._ck(self.lib.pbf_slab_set_bounds(self._h, x_lo, x_hi))
+    def slab_set_bounds(self, x_lo: int, x_hi: int, ghost_layers: int = 2):
+        self._ck(self.lib.pbf_slab_set_bounds(self._h, x_lo, x_hi, ghost_layers))
 
-    def slab_partition(self, d_left: int, d_right: int, max_records: int):
-        counts = (C.c_uint32 * 3)()
-        self._ck(self.lib.pbf_slab_partition(self._h, C.c_void_p(d_left), C.c_void_p(d_right),
-                                             max_records, C.byref(counts)))
-        self.n = int(counts[0])
-        return int(counts[0]), int(counts[1]), int(counts[2])
+    def slab_split(self, d_mig_left: int, d_mig_right: int, d_ghost_left: int, d_ghost_right: int,
+                   max_records: int, d_counts: int):
+        self._ck(self.lib.pbf_slab_split(self._h, C.c_void_p(d_mig_left), C.c_void_p(d_mig_right),
+                                         C.c_void_p(d_ghost_left), C.c_void_p(d_ghost_right),
+                                         max_records, C.c_void_p(d_counts)))
 
-    def slab_append(self, d_records: int, count: int, ghost_side: int = -1):
-        self._ck(self.lib.pbf_slab_append(self._h, C.c_void_p(d_records or None), count, ghost_side))
-        self.n += count
+    def slab_split_done(self, counts):
+        arr = (C.c_uint32 * 6)(*[int(v) for v in counts])
+        self._ck(self.lib.pbf_slab_split_done(self._h, C.byref(arr)))
+        self.n = int(self.lib.pbf_num_particles(self._h))
 
-    def slab_pack_ghosts(self, side: int, d_out: int, max_records: int) -> int:
-        k = C.c_uint32()
-        self._ck(self.lib.pbf_slab_pack_ghosts(self._h, side, C.c_void_p(d_out), max_records, C.byref(k)))
-        return int(k.value)
+    def slab_append_owned(self, d_left: int, count_left: int, d_right: int = 0, count_right: int = 0):
+        self._ck(self.lib.pbf_slab_append_owned(self._h, C.c_void_p(d_left or None), count_left,
+                                                C.c_void_p(d_right or None), count_right))
+        self.n = int(self.lib.pbf_num_particles(self._h))
 
-    def slab_pack_halo(self, side: int, what: int, d_out: int):
-        self._ck(self.lib.pbf_slab_pack_halo(self._h, side, what, C.c_void_p(d_out or None)))
+    def slab_append_ghosts(self, d_left: int, count_left: int, d_right: int, count_right: int):
+        self._ck(self.lib.pbf_slab_append_ghosts(self._h, C.c_void_p(d_left or None), count_left,
+                                                 C.c_void_p(d_right or None), count_right))
+        self.n = int(self.lib.pbf_num_particles(self._h))
 
-    def slab_unpack_halo(self, side: int, what: int, d_in: int, count: int):
-        self._ck(self.lib.pbf_slab_unpack_halo(self._h, side, what, C.c_void_p(d_in or None), count))
+    def slab_pack_halo(self, what: int, d_left: int, d_right: int):
+        self._ck(self.lib.pbf_slab_pack_halo(self._h, what, C.c_void_p(d_left or None),
+                                             C.c_void_p(d_right or None)))
+
+    def slab_unpack_halo(self, what: int, d_left: int, count_left: int, d_right: int, count_right: int):
+        self._ck(self.lib.pbf_slab_unpack_halo(self._h, what, C.c_void_p(d_left or None), count_left,
+                                               C.c_void_p(d_right or None), count_right))
 
     def slab_export(self, d_records: int, max_records: int) -> int:
         k = C.c_uint32()

@@ -879,7 +879,7 @@ __global__ __launch_bounds__(BLOCK) void k_xsph(const float4* __restrict__ pos,
 constexpr uint32_t GHOST_BIT = 0x80000000u;
 
 struct SlabCounters {
-    uint32_t stay, left, right, ghosts, exported;
+    uint32_t exported;
 };
 
 __device__ __forceinline__ void write_record(float* rec, const float4& p, const float4& v,
@@ -890,31 +890,116 @@ __device__ __forceinline__ void write_record(float* rec, const float4& p, const 
     r[2] = make_float4(q.x, q.y, q.z, 0.f);
 }
 
-// after predict: drop ghosts, keep stayers (compacted into the spare buffers), pack leavers
-__global__ __launch_bounds__(BLOCK) void k_slab_partition(
+// counter slots of the split (device memory the caller may forward to its neighbours)
+enum { SPLIT_STAY = 0, SPLIT_TOO_FAR = 1, SPLIT_MIG_LEFT = 2, SPLIT_GHOST_LEFT = 3, SPLIT_MIG_RIGHT = 4, SPLIT_GHOST_RIGHT = 5 };
+
+constexpr int SPLIT_ITEMS = 8;                       // particles per thread
+constexpr int SPLIT_CHUNK = BLOCK * SPLIT_ITEMS;     // particles per block
+constexpr int SPLIT_TILES = SPLIT_ITEMS * (BLOCK / 64);   // wave-sized tiles per block (<= 64)
+
+// after predict, one pass: drop last step's ghosts, keep stayers (compacted into the spare
+// buffers), pack leavers as migrant records, pack the stayers of the boundary cell planes as
+// ghost records (side 0: cells [lo0, hi0), side 1: [lo1, hi1); a thin slab's particle may be in
+// both) and remember their compacted index for the halo refreshes.
+// Same-address atomics retire about one per 10 ns, so a block classifies SPLIT_CHUNK particles,
+// scans its wave tiles in LDS and reserves its output ranges with ONE atomic per counter.
+__global__ __launch_bounds__(BLOCK) void k_slab_split(
     const float4* __restrict__ pos, const float4* __restrict__ vel, const float4* __restrict__ prd,
     const uint32_t* __restrict__ id, uint32_t n, float spacing, int32_t x_lo, int32_t x_hi,
-    float4* __restrict__ pos_o, float4* __restrict__ vel_o, float4* __restrict__ prd_o,
-    uint32_t* __restrict__ id_o, float* __restrict__ rec_left, float* __restrict__ rec_right,
-    uint32_t max_records, SlabCounters* __restrict__ cnt) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t pid = id[i];
-    if (pid & GHOST_BIT) return;
-    const float4 q = prd[i];
-    const int32_t cx = floor_cell(q.x, spacing);
-    if (cx < x_lo) {
-        uint32_t s = atomicAdd(&cnt->left, 1u);
-        if (s < max_records) write_record(rec_left + 12 * (size_t)s, pos[i], vel[i], pid, q);
-    } else if (cx >= x_hi) {
-        uint32_t s = atomicAdd(&cnt->right, 1u);
-        if (s < max_records) write_record(rec_right + 12 * (size_t)s, pos[i], vel[i], pid, q);
-    } else {
-        uint32_t s = atomicAdd(&cnt->stay, 1u);
-        pos_o[s] = pos[i];
-        vel_o[s] = vel[i];
-        prd_o[s] = q;
-        id_o[s] = pid;
+    int32_t lo0, int32_t hi0, int32_t lo1, int32_t hi1, float4* __restrict__ pos_o,
+    float4* __restrict__ vel_o, float4* __restrict__ prd_o, uint32_t* __restrict__ id_o,
+    float* __restrict__ mig0, float* __restrict__ mig1, float* __restrict__ gh0,
+    float* __restrict__ gh1, uint32_t max_records, uint32_t* __restrict__ blist0,
+    uint32_t* __restrict__ blist1, uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t tile[3][SPLIT_TILES];
+    __shared__ uint32_t block_base[3];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t chunk0 = blockIdx.x * SPLIT_CHUNK;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // per item: bits 0-1 class (0 none, 1 stay, 2 to the left, 3 to the right), bit 2 / 3 = in
+    // the left / right boundary planes
+    uint32_t flags = 0;
+    uint32_t too_far = 0;
+#pragma unroll
+    for (int k = 0; k < SPLIT_ITEMS; ++k) {
+        const uint32_t i = chunk0 + k * BLOCK + threadIdx.x;
+        uint32_t pid = GHOST_BIT;
+        if (i < n) pid = id[i];
+        uint32_t f = 0;
+        if (!(pid & GHOST_BIT)) {
+            const int32_t cx = floor_cell(prd[i].x, spacing);
+            if (cx < x_lo) {
+                f = 2;
+                too_far += (int64_t)cx < (int64_t)x_lo - (hi0 - lo0);
+            } else if (cx >= x_hi) {
+                f = 3;
+                too_far += (int64_t)cx >= (int64_t)x_hi + (hi1 - lo1);
+            } else {
+                f = 1u | ((cx >= lo0 && cx < hi0) ? 4u : 0u) | ((cx >= lo1 && cx < hi1) ? 8u : 0u);
+            }
+        }
+        flags |= f << (4 * k);
+        const unsigned long long ms = __ballot((f & 3u) == 1u), m0 = __ballot(f & 4u), m1 = __ballot(f & 8u);
+        if (lane == 0) {
+            tile[0][k * (BLOCK / 64) + wave] = (uint32_t)__popcll(ms);
+            tile[1][k * (BLOCK / 64) + wave] = (uint32_t)__popcll(m0);
+            tile[2][k * (BLOCK / 64) + wave] = (uint32_t)__popcll(m1);
+        }
+    }
+    if (too_far) atomicAdd(&cnt[SPLIT_TOO_FAR], too_far);
+    __syncthreads();
+    if (wave == 0) {
+        const int slot[3] = {SPLIT_STAY, SPLIT_GHOST_LEFT, SPLIT_GHOST_RIGHT};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const uint32_t v = lane < SPLIT_TILES ? tile[a][lane] : 0u;
+            uint32_t inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t t = __shfl_up(inc, d, 64);
+                if ((int)lane >= d) inc += t;
+            }
+            const uint32_t total = __shfl(inc, 63, 64);
+            if (lane < SPLIT_TILES) tile[a][lane] = inc - v;
+            if (lane == 0) block_base[a] = total ? atomicAdd(&cnt[slot[a]], total) : 0u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SPLIT_ITEMS; ++k) {
+        const uint32_t i = chunk0 + k * BLOCK + threadIdx.x;
+        const uint32_t f = (flags >> (4 * k)) & 15u;
+        const bool stay = (f & 3u) == 1u, in0 = f & 4u, in1 = f & 8u;
+        const unsigned long long ms = __ballot(stay), m0 = __ballot(in0), m1 = __ballot(in1);
+        if (!f) continue;
+        const int t = k * (BLOCK / 64) + wave;
+        const float4 p = pos[i], v = vel[i], q = prd[i];
+        const uint32_t pid = id[i];
+        if (stay) {
+            const uint32_t s = block_base[0] + tile[0][t] + (uint32_t)__popcll(ms & lt);
+            pos_o[s] = p;
+            vel_o[s] = v;
+            prd_o[s] = q;
+            id_o[s] = pid;
+            if (in0) {
+                const uint32_t g = block_base[1] + tile[1][t] + (uint32_t)__popcll(m0 & lt);
+                if (g < max_records) {
+                    write_record(gh0 + 12 * (size_t)g, p, v, pid, q);
+                    blist0[g] = s;
+                }
+            }
+            if (in1) {
+                const uint32_t g = block_base[2] + tile[2][t] + (uint32_t)__popcll(m1 & lt);
+                if (g < max_records) {
+                    write_record(gh1 + 12 * (size_t)g, p, v, pid, q);
+                    blist1[g] = s;
+                }
+            }
+        } else {   // leavers are rare: plain atomics
+            float* mig = (f & 3u) == 2u ? mig0 : mig1;
+            const uint32_t m = atomicAdd(&cnt[(f & 3u) == 2u ? SPLIT_MIG_LEFT : SPLIT_MIG_RIGHT], 1u);
+            if (m < max_records) write_record(mig + 12 * (size_t)m, p, v, pid, q);
+        }
     }
 }
 
@@ -935,44 +1020,45 @@ __global__ __launch_bounds__(BLOCK) void k_slab_append(const float* __restrict__
     id[base + i] = pid;
 }
 
-// owned particles in the boundary cell plane `plane` -> ghost records + boundary list
-__global__ __launch_bounds__(BLOCK) void k_slab_pack_ghosts(
-    const float4* __restrict__ pos, const float4* __restrict__ vel, const float4* __restrict__ prd,
-    const uint32_t* __restrict__ id, uint32_t n, float spacing, int32_t plane,
-    float* __restrict__ rec, uint32_t max_records, uint32_t* __restrict__ blist,
-    uint32_t* __restrict__ counter) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t pid = id[i];
-    if (pid & GHOST_BIT) return;
-    const float4 q = prd[i];
-    if (floor_cell(q.x, spacing) != plane) return;
-    uint32_t s = atomicAdd(counter, 1u);
-    if (s < max_records) {
-        write_record(rec + 12 * (size_t)s, pos[i], vel[i], pid, q);
-        blist[s] = i;
+// migrants that arrived from one side join that side's boundary list: blist[at + e] = base + e
+__global__ __launch_bounds__(BLOCK) void k_slab_list_range(uint32_t* __restrict__ blist, uint32_t at,
+                                                           uint32_t base, uint32_t count) {
+    uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e < count) blist[at + e] = base + e;
+}
+
+// halo refresh, both sides in one launch: boundary list (pre-sort indices) -> sorted slots ->
+// float4 payload
+__global__ __launch_bounds__(BLOCK) void k_slab_pack_halo(
+    const float4* __restrict__ src, const uint32_t* __restrict__ blist0,
+    const uint32_t* __restrict__ blist1, const uint32_t* __restrict__ slot_of, uint32_t count0,
+    uint32_t count1, float4* __restrict__ out0, float4* __restrict__ out1) {
+    uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e < count0) {
+        out0[e] = src[slot_of[blist0[e]]];
+    } else if (e < count0 + count1) {
+        e -= count0;
+        out1[e] = src[slot_of[blist1[e]]];
     }
 }
 
-// halo refresh: boundary list (pre-sort indices) -> sorted slots -> float4 payload
-__global__ __launch_bounds__(BLOCK) void k_slab_pack_halo(const float4* __restrict__ src,
-                                                          const uint32_t* __restrict__ blist,
-                                                          const uint32_t* __restrict__ slot_of,
-                                                          uint32_t count, float4* __restrict__ out) {
+__global__ __launch_bounds__(BLOCK) void k_slab_unpack_halo(
+    float4* __restrict__ dst, const uint32_t* __restrict__ slot_of, uint32_t base0, uint32_t count0,
+    uint32_t base1, uint32_t count1, const float4* __restrict__ in0, const float4* __restrict__ in1,
+    int keep_w) {
     uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= count) return;
-    out[e] = src[slot_of[blist[e]]];
-}
-
-__global__ __launch_bounds__(BLOCK) void k_slab_unpack_halo(float4* __restrict__ dst,
-                                                            const uint32_t* __restrict__ slot_of,
-                                                            uint32_t ghost_base, uint32_t count,
-                                                            const float4* __restrict__ in,
-                                                            int keep_w) {
-    uint32_t e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= count) return;
-    const uint32_t slot = slot_of[ghost_base + e];
-    float4 v = in[e];
+    uint32_t slot;
+    float4 v;
+    if (e < count0) {
+        slot = slot_of[base0 + e];
+        v = in0[e];
+    } else if (e < count0 + count1) {
+        e -= count0;
+        slot = slot_of[base1 + e];
+        v = in1[e];
+    } else {
+        return;
+    }
     if (keep_w) v.w = dst[slot].w;
     dst[slot] = v;
 }
@@ -1148,11 +1234,14 @@ struct pbf_ctx {
     bool first_frame = true;
     // slab decomposition state
     bool slab = false;
-    int32_t x_lo = INT32_MIN, x_hi = INT32_MAX;
+    int32_t x_lo = INT32_MIN, x_hi = INT32_MAX, ghost_layers = 1;
     uint32_t* slot_of = nullptr;          // pre-sort index -> sorted slot of the last sort
     uint32_t* blist[2] = {nullptr, nullptr};  // boundary-plane particles (pre-sort indices)
     uint32_t bcount[2] = {0, 0};
     uint32_t ghost_base[2] = {0, 0}, ghost_count[2] = {0, 0};
+    bool split_pending = false, in_exchange = false;
+    const float* mig_out[2] = {nullptr, nullptr};   // this step's migrant records (caller's buffers)
+    uint32_t mig_out_count[2] = {0, 0}, split_max = 0;
     SlabCounters* slab_cnt = nullptr;
     bool owns_stream = true;
     bool uniform = false;      // every particle has uniform_mass (no per-neighbour mass gather)
@@ -1629,6 +1718,8 @@ int pbf_predict(pbf_ctx* c, float dt) {
 
 int pbf_build_grid(pbf_ctx* c) {
     ENTER(c);
+    if (c->split_pending || c->in_exchange)
+        return fail(c, PBF_ERR_INVALID, "slab exchange in flight: split_done / append_ghosts come first");
     if (!c->keyed && c->n) {
         k_rekey<<<nblocks(c->n), BLOCK, 0, c->stream>>>(c->prd[c->prd_cur], c->key, c->cell_count,
                                                         c->n, make_grid(c->P));
@@ -1799,65 +1890,85 @@ int pbf_set_stream(pbf_ctx* c, void* stream) {
     return PBF_OK;
 }
 
-int pbf_slab_set_bounds(pbf_ctx* c, int32_t x_lo, int32_t x_hi) {
+int pbf_slab_set_bounds(pbf_ctx* c, int32_t x_lo, int32_t x_hi, int32_t ghost_layers) {
     if (!c) return PBF_ERR_INVALID;
     if (x_lo >= x_hi) return fail(c, PBF_ERR_INVALID, "empty slab");
+    if (ghost_layers < 1 || ghost_layers > 8) return fail(c, PBF_ERR_INVALID, "ghost_layers must be in [1, 8]");
     if (c->P.rest_density_mode != PBF_RHO0_FIXED)
         return fail(c, PBF_ERR_INVALID, "slab mode needs PBF_RHO0_FIXED (the first-frame mean is a serial global sum)");
     c->slab = true;
     c->x_lo = x_lo;
     c->x_hi = x_hi;
+    c->ghost_layers = ghost_layers;
     return PBF_OK;
 }
 
-int pbf_slab_partition(pbf_ctx* c, void* d_left, void* d_right, uint32_t max_records,
-                       uint32_t counts[3]) {
+int pbf_slab_split(pbf_ctx* c, void* d_mig_left, void* d_mig_right, void* d_ghost_left,
+                   void* d_ghost_right, uint32_t max_records, void* d_counts) {
     ENTER(c);
     if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
-    if (!counts) return fail(c, PBF_ERR_INVALID, "null counts");
-    HIP_CK(c, hipMemsetAsync(c->slab_cnt, 0, sizeof(SlabCounters), c->stream));
+    if (c->split_pending) return fail(c, PBF_ERR_INVALID, "pbf_slab_split_done has not been called");
+    if (!d_mig_left || !d_mig_right || !d_ghost_left || !d_ghost_right || !d_counts || !max_records)
+        return fail(c, PBF_ERR_INVALID, "bad argument");
+    HIP_CK(c, hipMemsetAsync(d_counts, 0, 6 * sizeof(uint32_t), c->stream));
     const int s = c->cur, d = 1 - c->cur;
     const int ps_ = c->prd_cur, pd = (c->prd_cur + 1) % 3;
+    if (max_records > c->cap) max_records = c->cap;   // the boundary lists hold cap entries
     if (c->n) {
-        k_slab_partition<<<nblocks(c->n), BLOCK, 0, c->stream>>>(
+        // empty plane ranges for open ends
+        const bool open0 = c->x_lo == INT32_MIN, open1 = c->x_hi == INT32_MAX;
+        const int32_t L = c->ghost_layers;
+        const int32_t lo0 = open0 ? 0 : c->x_lo, hi0 = open0 ? 0 : (int32_t)((int64_t)c->x_lo + L);
+        const int32_t lo1 = open1 ? 0 : (int32_t)((int64_t)c->x_hi - L), hi1 = open1 ? 0 : c->x_hi;
+        k_slab_split<<<(c->n + SPLIT_CHUNK - 1) / SPLIT_CHUNK, BLOCK, 0, c->stream>>>(
             c->pos[s], c->vel[s], c->prd[ps_], c->id[s], c->n, c->P.grid_spacing, c->x_lo, c->x_hi,
-            c->pos[d], c->vel[d], c->prd[pd], c->id[d], (float*)d_left, (float*)d_right, max_records,
-            c->slab_cnt);
+            lo0, hi0, lo1, hi1, c->pos[d], c->vel[d], c->prd[pd], c->id[d], (float*)d_mig_left,
+            (float*)d_mig_right, (float*)d_ghost_left, (float*)d_ghost_right, max_records,
+            c->blist[0], c->blist[1], (uint32_t*)d_counts);
         LAUNCH_CK(c);
     }
-    SlabCounters h;
-    HIP_CK(c, hipMemcpyAsync(&h, c->slab_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIP_CK(c, hipStreamSynchronize(c->stream));
-    if (h.left > max_records || h.right > max_records)
-        return fail(c, PBF_ERR_CAPACITY, "migration buffer too small");
     c->cur = d;
     c->prd_cur = pd;
-    c->n = h.stay;
     c->keyed = false;
     c->grid_valid = false;
-    c->ghost_count[0] = c->ghost_count[1] = 0;
-    c->bcount[0] = c->bcount[1] = 0;
-    counts[0] = h.stay;
-    counts[1] = h.left;
-    counts[2] = h.right;
+    c->split_pending = true;
+    c->split_max = max_records;
+    c->mig_out[0] = (const float*)d_mig_left;
+    c->mig_out[1] = (const float*)d_mig_right;
     return PBF_OK;
 }
 
-int pbf_slab_append(pbf_ctx* c, const void* d_records, uint32_t count, int32_t ghost_side) {
+int pbf_slab_split_done(pbf_ctx* c, const uint32_t counts[6]) {
     ENTER(c);
-    if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
-    if (ghost_side < -1 || ghost_side > 1) return fail(c, PBF_ERR_INVALID, "bad ghost_side");
+    if (!c->split_pending) return fail(c, PBF_ERR_INVALID, "no split in flight");
+    if (!counts) return fail(c, PBF_ERR_INVALID, "null counts");
+    c->split_pending = false;
+    c->n = 0;
+    c->ghost_count[0] = c->ghost_count[1] = 0;
+    c->bcount[0] = c->bcount[1] = 0;
+    c->mig_out_count[0] = c->mig_out_count[1] = 0;
+    if (counts[SPLIT_STAY] > c->cap) return fail(c, PBF_ERR_INVALID, "stay count exceeds capacity (wrong counts?)");
+    if (counts[SPLIT_TOO_FAR])
+        return fail(c, PBF_ERR_INVALID, "a particle crossed more than ghost_layers cell planes beyond its slab in one sub-step");
+    if (counts[SPLIT_MIG_LEFT] > c->split_max || counts[SPLIT_MIG_RIGHT] > c->split_max)
+        return fail(c, PBF_ERR_CAPACITY, "migration buffer too small");
+    if (counts[SPLIT_GHOST_LEFT] > c->split_max || counts[SPLIT_GHOST_RIGHT] > c->split_max)
+        return fail(c, PBF_ERR_CAPACITY, "ghost buffer too small");
+    c->n = counts[SPLIT_STAY];
+    c->bcount[0] = counts[SPLIT_GHOST_LEFT];
+    c->bcount[1] = counts[SPLIT_GHOST_RIGHT];
+    c->mig_out_count[0] = counts[SPLIT_MIG_LEFT];
+    c->mig_out_count[1] = counts[SPLIT_MIG_RIGHT];
+    c->in_exchange = true;
+    return PBF_OK;
+}
+
+static int slab_append_one(pbf_ctx* c, const void* d_records, uint32_t count, bool ghost) {
     if ((uint64_t)c->n + count > c->cap) return fail(c, PBF_ERR_CAPACITY, "slab exceeds ctx capacity");
-    if (ghost_side >= 0) {
-        c->ghost_base[ghost_side] = c->n;
-        c->ghost_count[ghost_side] = count;
-    } else if (c->ghost_count[0] || c->ghost_count[1]) {
-        return fail(c, PBF_ERR_INVALID, "owned particles must be appended before ghosts");
-    }
     if (count) {
         if (!d_records) return fail(c, PBF_ERR_INVALID, "null records");
         k_slab_append<<<nblocks(count), BLOCK, 0, c->stream>>>(
-            (const float*)d_records, count, c->n, ghost_side >= 0 ? GHOST_BIT : 0u, c->pos[c->cur],
+            (const float*)d_records, count, c->n, ghost ? GHOST_BIT : 0u, c->pos[c->cur],
             c->vel[c->cur], c->prd[c->prd_cur], c->id[c->cur]);
         LAUNCH_CK(c);
     }
@@ -1866,29 +1977,50 @@ int pbf_slab_append(pbf_ctx* c, const void* d_records, uint32_t count, int32_t g
     return PBF_OK;
 }
 
-int pbf_slab_pack_ghosts(pbf_ctx* c, int32_t side, void* d_out, uint32_t max_records,
-                         uint32_t* count) {
+int pbf_slab_append_owned(pbf_ctx* c, const void* d_from_left, uint32_t count_left,
+                          const void* d_from_right, uint32_t count_right) {
     ENTER(c);
     if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
-    if (side < 0 || side > 1 || !count) return fail(c, PBF_ERR_INVALID, "bad argument");
-    *count = 0;
-    c->bcount[side] = 0;
-    const int32_t plane = side == 0 ? c->x_lo : c->x_hi - 1;
-    const bool open_end = side == 0 ? c->x_lo == INT32_MIN : c->x_hi == INT32_MAX;
-    if (open_end || !c->n) return PBF_OK;
-    uint32_t* counter = &c->slab_cnt->ghosts;
-    HIP_CK(c, hipMemsetAsync(counter, 0, 4, c->stream));
-    if (max_records > c->cap) max_records = c->cap;
-    k_slab_pack_ghosts<<<nblocks(c->n), BLOCK, 0, c->stream>>>(
-        c->pos[c->cur], c->vel[c->cur], c->prd[c->prd_cur], c->id[c->cur], c->n, c->P.grid_spacing,
-        plane, (float*)d_out, max_records, c->blist[side], counter);
-    LAUNCH_CK(c);
-    uint32_t h = 0;
-    HIP_CK(c, hipMemcpyAsync(&h, counter, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_CK(c, hipStreamSynchronize(c->stream));
-    if (h > max_records) return fail(c, PBF_ERR_CAPACITY, "ghost buffer too small");
-    c->bcount[side] = h;
-    *count = h;
+    if (c->split_pending) return fail(c, PBF_ERR_INVALID, "pbf_slab_split_done has not been called");
+    if (c->ghost_count[0] || c->ghost_count[1])
+        return fail(c, PBF_ERR_INVALID, "owned particles must be appended before ghosts");
+    const void* rec[2] = {d_from_left, d_from_right};
+    const uint32_t cnt[2] = {count_left, count_right};
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t base = c->n;
+        int rc = slab_append_one(c, rec[side], cnt[side], false);
+        if (rc) return rc;
+        if (c->in_exchange && cnt[side]) {
+            // the sender keeps its migrants as ghosts: list them for the halo refreshes
+            if ((uint64_t)c->bcount[side] + cnt[side] > c->cap)
+                return fail(c, PBF_ERR_CAPACITY, "boundary list full");
+            k_slab_list_range<<<nblocks(cnt[side]), BLOCK, 0, c->stream>>>(c->blist[side], c->bcount[side],
+                                                                          base, cnt[side]);
+            LAUNCH_CK(c);
+            c->bcount[side] += cnt[side];
+        }
+    }
+    return PBF_OK;
+}
+
+int pbf_slab_append_ghosts(pbf_ctx* c, const void* d_from_left, uint32_t count_left,
+                           const void* d_from_right, uint32_t count_right) {
+    ENTER(c);
+    if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
+    if (!c->in_exchange) return fail(c, PBF_ERR_INVALID, "pbf_slab_split / pbf_slab_split_done come first");
+    const void* rec[2] = {d_from_left, d_from_right};
+    const uint32_t cnt[2] = {count_left, count_right};
+    for (int side = 0; side < 2; ++side) {
+        c->ghost_base[side] = c->n;
+        int rc = slab_append_one(c, rec[side], cnt[side], true);
+        if (rc) return rc;
+        // this slab's own migrants to that side stay here as ghosts (their new owner lists them
+        // in the same order, right after its boundary-plane particles)
+        rc = slab_append_one(c, c->mig_out[side], c->mig_out_count[side], true);
+        if (rc) return rc;
+        c->ghost_count[side] = c->n - c->ghost_base[side];
+    }
+    c->in_exchange = false;
     return PBF_OK;
 }
 
@@ -1902,30 +2034,36 @@ static float4* halo_array(pbf_ctx* c, int32_t what) {
     }
 }
 
-int pbf_slab_pack_halo(pbf_ctx* c, int32_t side, int32_t what, void* d_out) {
+int pbf_slab_pack_halo(pbf_ctx* c, int32_t what, void* d_left, void* d_right) {
     ENTER(c);
     if (!c->slab || !c->grid_valid) return fail(c, PBF_ERR_INVALID, "halo refresh needs a built slab grid");
     float4* src = halo_array(c, what);
-    if (side < 0 || side > 1 || !src) return fail(c, PBF_ERR_INVALID, "bad argument");
-    const uint32_t k = c->bcount[side];
-    if (!k) return PBF_OK;
-    if (!d_out) return fail(c, PBF_ERR_INVALID, "null buffer");
-    k_slab_pack_halo<<<nblocks(k), BLOCK, 0, c->stream>>>(src, c->blist[side], c->slot_of, k, (float4*)d_out);
+    if (!src) return fail(c, PBF_ERR_INVALID, "bad argument");
+    const uint32_t k0 = c->bcount[0], k1 = c->bcount[1];
+    if (!(k0 + k1)) return PBF_OK;
+    if ((k0 && !d_left) || (k1 && !d_right)) return fail(c, PBF_ERR_INVALID, "null buffer");
+    k_slab_pack_halo<<<nblocks(k0 + k1), BLOCK, 0, c->stream>>>(
+        src, c->blist[0], c->blist[1], c->slot_of, k0, k1, (float4*)d_left, (float4*)d_right);
     LAUNCH_CK(c);
     return PBF_OK;
 }
 
-int pbf_slab_unpack_halo(pbf_ctx* c, int32_t side, int32_t what, const void* d_in, uint32_t count) {
+int pbf_slab_unpack_halo(pbf_ctx* c, int32_t what, const void* d_from_left, uint32_t count_left,
+                         const void* d_from_right, uint32_t count_right) {
     ENTER(c);
     if (!c->slab || !c->grid_valid) return fail(c, PBF_ERR_INVALID, "halo refresh needs a built slab grid");
     float4* dst = halo_array(c, what);
-    if (side < 0 || side > 1 || !dst) return fail(c, PBF_ERR_INVALID, "bad argument");
-    if (count != c->ghost_count[side]) return fail(c, PBF_ERR_INVALID, "halo size differs from the ghost count");
-    if (!count) return PBF_OK;
-    if (!d_in) return fail(c, PBF_ERR_INVALID, "null buffer");
+    if (!dst) return fail(c, PBF_ERR_INVALID, "bad argument");
+    if (count_left != c->ghost_count[0] || count_right != c->ghost_count[1])
+        return fail(c, PBF_ERR_INVALID, "halo size differs from the ghost count");
+    if (c->in_exchange) return fail(c, PBF_ERR_INVALID, "ghosts have not been appended");
+    if (!(count_left + count_right)) return PBF_OK;
+    if ((count_left && !d_from_left) || (count_right && !d_from_right))
+        return fail(c, PBF_ERR_INVALID, "null buffer");
     // positions keep their own mass in .w; everything else is replaced whole
-    k_slab_unpack_halo<<<nblocks(count), BLOCK, 0, c->stream>>>(dst, c->slot_of, c->ghost_base[side],
-                                                              count, (const float4*)d_in, what == 3);
+    k_slab_unpack_halo<<<nblocks(count_left + count_right), BLOCK, 0, c->stream>>>(
+        dst, c->slot_of, c->ghost_base[0], count_left, c->ghost_base[1], count_right,
+        (const float4*)d_from_left, (const float4*)d_from_right, what == 3);
     LAUNCH_CK(c);
     return PBF_OK;
 }

@@ -4,10 +4,21 @@ One process per GPU; rank r owns the grid cells whose x index lies in [planes[r]
 Per sub-step (ghost membership and neighbour tables are frozen for the sub-step, as the
 reference freezes its neighbour lists across solver iterations, Simulation.cpp:112-118):
 
-    predict+collide -> migrate leavers (point-to-point, left/right) -> exchange the boundary
-    cell planes as ghosts -> cell grid / counting sort / neighbour table over owned+ghost ->
-    iterations x { lambda ; refresh ghost lambda ; delta-p ; refresh ghost positions } ->
-    velocity update (+ ghost refreshes between the viscosity stages)
+    predict+collide -> split (one pass: stayers compacted, leavers packed as migrants, the
+    boundary cell planes packed as ghosts) -> counts to the neighbours, ONE host synchronisation
+    -> migrants + ghosts to the neighbours in one batch -> cell grid / counting sort / neighbour
+    table over owned+ghost -> iterations x { lambda ; delta-p ; refresh ghost positions } ->
+    velocity update (+ one ghost velocity refresh between vorticity and XSPH)
+
+A particle that leaves towards a neighbour stays behind as a ghost (it lands in the neighbour's
+boundary planes, which is exactly what this slab needs from there), and its new owner lists it
+with its boundary-plane particles, so migration and ghost exchange need no second round.
+
+Two cell planes per side travel as ghosts (GHOST_LAYERS): every sweep also runs over the ghosts,
+and with the second layer present the inner layer's lambda / vorticity comes out of the local
+sweep bit-identical to the owner's, so only the positions moved by delta-p (and the
+velocities changed by the vorticity force) are refreshed.  With one layer the lambda and omega
+of the ghosts are refreshed from their owners as well.
 
 The exchange is neighbour point-to-point over RCCL (torch.distributed "nccl" backend: one
 direct xGMI link per slab pair, no ring) with payloads packed/unpacked by the C-ABI slab entry
@@ -25,6 +36,7 @@ from .binding import PbfContext, PbfParams
 INT32_MIN, INT32_MAX = -(2 ** 31), 2 ** 31 - 1
 REC = 12  # floats per particle record: pos.xyz, mass, vel.xyz, id bits, pred.xyz, 0
 HALO_PRED_LAMBDA, HALO_VELOCITY, HALO_OMEGA, HALO_POSITION = 0, 1, 2, 3
+GHOST_LAYERS = 2
 
 
 # --------------------------------------------------------------------------- partitioning
@@ -34,9 +46,12 @@ def cell_x(pos_x, spacing):
     return np.floor(np.asarray(pos_x, np.float32) / np.float32(spacing)).astype(np.int64)
 
 
-def split_planes(pos, spacing, world):
+def split_planes(pos, spacing, world, min_width=2 * GHOST_LAYERS):
     """Cell planes planes[0..world] (open ends) that split the particles into `world` slabs of
-    near-equal count; boundaries snap to cell planes so a cell belongs to exactly one rank."""
+    near-equal count; boundaries snap to cell planes so a cell belongs to exactly one rank.
+    Interior slabs are at least min_width cells wide: the ghost layers of a slab come from its
+    direct neighbours only, and a migrant (which lands at most GHOST_LAYERS planes deep) must
+    not land in the far boundary planes of its new owner."""
     cx = cell_x(pos[:, 0], spacing)
     planes = [INT32_MIN]
     if world > 1:
@@ -47,7 +62,7 @@ def split_planes(pos, spacing, world):
         for r in range(1, world):
             k = int(np.searchsorted(csum, total * r / world, side="left")) + 1
             plane = lo + k
-            plane = max(plane, planes[-1] + 1 if planes[-1] != INT32_MIN else plane)
+            plane = max(plane, planes[-1] + min_width if planes[-1] != INT32_MIN else plane)
             planes.append(plane)
     planes.append(INT32_MAX)
     return planes
@@ -76,7 +91,7 @@ class HipSlabBackend:
     ops issued by torch.distributed are ordered with them without host synchronisation."""
 
     def __init__(self, params: PbfParams, colliders, uniform_mass, x_lo, x_hi, device=0,
-                 max_records=None):
+                 max_records=None, ghost_layers=GHOST_LAYERS):
         import torch
         self.torch = torch
         self.device = torch.device("cuda", device)
@@ -85,14 +100,19 @@ class HipSlabBackend:
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.ctx.upload(np.zeros((0, 3), np.float32), uniform_mass=uniform_mass)
         self.ctx.set_colliders(colliders)
-        self.ctx.slab_set_bounds(x_lo, x_hi)
+        self.ctx.slab_set_bounds(x_lo, x_hi, ghost_layers)
+        self.ghost_layers = ghost_layers
         cap = int(params.capacity)
         self.max_records = int(max_records or max(65536, cap // 4))
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.send = [torch.empty((self.max_records, REC), **f32) for _ in range(2)]
+        self.mig = [torch.empty((self.max_records, REC), **f32) for _ in range(2)]
+        self.gh = [torch.empty((self.max_records, REC), **f32) for _ in range(2)]
         self.hsend = [torch.empty((self.max_records, 4), **f32) for _ in range(2)]
-        self.bcount = [0, 0]
-        self.gcount = [0, 0]
+        self.counts = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self.bcount = [0, 0]   # boundary-list sizes (what a halo refresh sends)
+        self.mcount = [0, 0]   # this step's migrants out (kept as ghosts)
+        self.gcount = [0, 0]   # ghosts per side (what a halo refresh receives)
+        self.in_step = False
         self.viscous = params.xsph_c != 0.0 or params.vorticity_eps != 0.0
         self.vorticity = params.vorticity_eps != 0.0
         self.xsph = params.xsph_c != 0.0
@@ -101,36 +121,42 @@ class HipSlabBackend:
     def to_backend(self, rec_np):
         return self.torch.from_numpy(np.ascontiguousarray(rec_np, np.float32)).to(self.device)
 
-    def empty(self, n, width):
-        return self.torch.empty((n, width), dtype=self.torch.float32, device=self.device)
-
     # -- protocol
     def predict(self, dt):
         self.ctx.predict(dt)
 
-    def partition(self):
-        _, nl, nr = self.ctx.slab_partition(self.send[0].data_ptr(), self.send[1].data_ptr(),
-                                            self.max_records)
+    def split_launch(self):
+        self.ctx.slab_split(self.mig[0].data_ptr(), self.mig[1].data_ptr(), self.gh[0].data_ptr(),
+                            self.gh[1].data_ptr(), self.max_records, self.counts.data_ptr())
+
+    def count_tensor(self):
+        """int32[8] on the slab's device: {stay, 0, mig_left, ghost_left, mig_right, ghost_right, 0, 0}"""
+        return self.counts
+
+    def split_finish(self, own):
+        self.ctx.slab_split_done(own[:6])
+        self.mcount = [own[2], own[4]]
+        self.bcount = [own[3], own[5]]
         self.gcount = [0, 0]
-        return self.send[0][:nl], self.send[1][:nr]
+        self.in_step = True
+        return ([self.mig[0][:own[2]], self.gh[0][:own[3]]], [self.mig[1][:own[4]], self.gh[1][:own[5]]])
 
-    def append_owned(self, rec):
-        if rec.shape[0]:
-            rec = rec.contiguous()
-            self.ctx.slab_append(rec.data_ptr(), rec.shape[0], -1)
+    def append_owned(self, from_left, from_right=None):
+        a = from_left.contiguous()
+        b = from_right.contiguous() if from_right is not None else a[:0]
+        if a.shape[0] + b.shape[0]:
+            self.ctx.slab_append_owned(a.data_ptr() if a.shape[0] else 0, a.shape[0],
+                                       b.data_ptr() if b.shape[0] else 0, b.shape[0])
+        if self.in_step:
+            self.bcount[0] += a.shape[0]
+            self.bcount[1] += b.shape[0]
 
-    def pack_ghosts(self):
-        out = []
-        for side in (0, 1):
-            k = self.ctx.slab_pack_ghosts(side, self.send[side].data_ptr(), self.max_records)
-            self.bcount[side] = k
-            out.append(self.send[side][:k])
-        return out[0], out[1]
-
-    def append_ghosts(self, rec, side):
-        rec = rec.contiguous()
-        self.gcount[side] = rec.shape[0]
-        self.ctx.slab_append(rec.data_ptr() if rec.shape[0] else 0, rec.shape[0], side)
+    def append_ghosts(self, from_left, from_right):
+        l, r = from_left.contiguous(), from_right.contiguous()
+        self.gcount = [l.shape[0] + self.mcount[0], r.shape[0] + self.mcount[1]]
+        self.ctx.slab_append_ghosts(l.data_ptr() if l.shape[0] else 0, l.shape[0],
+                                    r.data_ptr() if r.shape[0] else 0, r.shape[0])
+        self.in_step = False
 
     def build(self):
         self.ctx.build_grid()
@@ -142,23 +168,21 @@ class HipSlabBackend:
         self.ctx.solve_delta(dt)
 
     def halo_pack(self, what):
-        out = []
-        for side in (0, 1):
-            k = self.bcount[side]
-            self.ctx.slab_pack_halo(side, what, self.hsend[side].data_ptr())
-            out.append(self.hsend[side][:k])
-        return out[0], out[1]
+        kl, kr = self.bcount
+        self.ctx.slab_pack_halo(what, self.hsend[0].data_ptr(), self.hsend[1].data_ptr())
+        return self.hsend[0][:kl], self.hsend[1][:kr]
 
     def halo_unpack(self, what, from_left, from_right):
-        for side, t in ((0, from_left), (1, from_right)):
-            t = t.contiguous()
-            self.ctx.slab_unpack_halo(side, what, t.data_ptr() if t.shape[0] else 0, t.shape[0])
+        l, r = from_left.contiguous(), from_right.contiguous()
+        self.ctx.slab_unpack_halo(what, l.data_ptr() if l.shape[0] else 0, l.shape[0],
+                                  r.data_ptr() if r.shape[0] else 0, r.shape[0])
 
     def finalize_stage(self, stage, dt):
         self.ctx.finalize_stage(stage, dt)
 
     def export(self):
-        buf = self.empty(int(self.ctx.params.capacity), REC)
+        buf = self.torch.empty((int(self.ctx.params.capacity), REC), dtype=self.torch.float32,
+                               device=self.device)
         k = self.ctx.slab_export(buf.data_ptr(), buf.shape[0])
         return buf[:k].cpu().numpy()
 
@@ -174,11 +198,20 @@ class LocalExchange:
     def __init__(self, world):
         self.world = world
 
-    def run(self, outs, backends, width, recv_counts=None):
+    def counts(self, backends):
+        own = [[int(v) for v in b.count_tensor().cpu().tolist()] for b in backends]
+        res = []
+        for s in range(self.world):
+            fl = own[s - 1][4:6] if s > 0 else [0, 0]
+            fr = own[s + 1][2:4] if s < self.world - 1 else [0, 0]
+            res.append((own[s], fl, fr))
+        return res
+
+    def run(self, outs, backends, recv_counts=None):
         ins = []
         for s in range(self.world):
-            fl = outs[s - 1][1] if s > 0 else backends[s].empty(0, width)
-            fr = outs[s + 1][0] if s < self.world - 1 else backends[s].empty(0, width)
+            fl = outs[s - 1][1] if s > 0 else [t[:0] for t in outs[s][0]]
+            fr = outs[s + 1][0] if s < self.world - 1 else [t[:0] for t in outs[s][1]]
             ins.append((fl, fr))
         return ins
 
@@ -195,51 +228,60 @@ class TorchExchange:
         self.rank, self.world, self.group = rank, world, group
         self.backend = dist.get_backend(group)
         self.on_gpu = self.backend == "nccl"
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
 
-    def _wire(self, t):
-        if self.on_gpu:
-            return t.contiguous()
-        return t.detach().cpu().contiguous()
-
-    def run(self, outs, backends, width, recv_counts=None):
-        torch, dist = self.torch, self.dist
-        (to_left, to_right), b = outs[0], backends[0]
-        left = self.rank - 1 if self.rank > 0 else None
-        right = self.rank + 1 if self.rank < self.world - 1 else None
-        dev = to_left.device if self.on_gpu else torch.device("cpu")
-        if recv_counts is None:
-            snd = torch.tensor([to_left.shape[0], to_right.shape[0]], dtype=torch.int64, device=dev)
-            rcv = torch.zeros(2, dtype=torch.int64, device=dev)
-            ops = []
-            if left is not None:
-                ops += [dist.P2POp(dist.isend, snd[0:1], left, self.group),
-                        dist.P2POp(dist.irecv, rcv[0:1], left, self.group)]
-            if right is not None:
-                ops += [dist.P2POp(dist.isend, snd[1:2], right, self.group),
-                        dist.P2POp(dist.irecv, rcv[1:2], right, self.group)]
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            recv_counts = [int(v) for v in rcv.tolist()]
-        bufs = [torch.empty((recv_counts[0], width), dtype=torch.float32, device=dev),
-                torch.empty((recv_counts[1], width), dtype=torch.float32, device=dev)]
-        ops = []
-        keep = []
-        for peer, payload, buf in ((left, to_left, bufs[0]), (right, to_right, bufs[1])):
-            if peer is None:
-                continue
-            if payload.shape[0]:
-                w = self._wire(payload)
-                keep.append(w)
-                ops.append(dist.P2POp(dist.isend, w, peer, self.group))
-            if buf.shape[0]:
-                ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
+    def _batch(self, ops):
         if ops:
-            for w in dist.batch_isend_irecv(ops):
+            for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
-        if not self.on_gpu and to_left.device.type != "cpu":
-            bufs = [x.to(to_left.device) for x in bufs]
-        return [(bufs[0], bufs[1])]
+
+    def counts(self, backends):
+        """The split counters go to the neighbours device-to-device (nccl) before the one
+        read-back of the sub-step: own six counters + the two pairs received."""
+        torch, dist = self.torch, self.dist
+        c = backends[0].count_tensor()
+        if not self.on_gpu:
+            c = c.cpu()
+        r = torch.zeros(4, dtype=c.dtype, device=c.device)
+        ops = []
+        if self.left is not None:
+            ops += [dist.P2POp(dist.isend, c[2:4], self.left, self.group),
+                    dist.P2POp(dist.irecv, r[0:2], self.left, self.group)]
+        if self.right is not None:
+            ops += [dist.P2POp(dist.isend, c[4:6], self.right, self.group),
+                    dist.P2POp(dist.irecv, r[2:4], self.right, self.group)]
+        self._batch(ops)
+        allc = [int(v) for v in torch.cat([c[:6], r]).cpu().tolist()]
+        return [(allc[:6], allc[6:8], allc[8:10])]
+
+    def run(self, outs, backends, recv_counts):
+        """outs[0] = (payloads to the left, payloads to the right); recv_counts[0] = (row counts
+        from the left, from the right), position by position; one batch of sends/receives."""
+        torch, dist = self.torch, self.dist
+        to_left, to_right = outs[0]
+        n_left, n_right = recv_counts[0]
+        home = (to_left + to_right)[0].device
+        dev = home if self.on_gpu else torch.device("cpu")
+        ops, keep, got = [], [], []
+        for peer, payloads, sizes in ((self.left, to_left, n_left), (self.right, to_right, n_right)):
+            bufs = []
+            for t, k in zip(payloads, sizes):
+                buf = torch.empty((k if peer is not None else 0, t.shape[1]), dtype=t.dtype, device=dev)
+                bufs.append(buf)
+                if peer is None:
+                    continue
+                if t.shape[0]:
+                    w = t.contiguous() if self.on_gpu else t.detach().cpu().contiguous()
+                    keep.append(w)
+                    ops.append(dist.P2POp(dist.isend, w, peer, self.group))
+                if k:
+                    ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
+            got.append(bufs)
+        self._batch(ops)
+        if not self.on_gpu and home.type != "cpu":
+            got = [[x.to(home) for x in bufs] for bufs in got]
+        return [(got[0], got[1])]
 
 
 # --------------------------------------------------------------------------- orchestration
@@ -254,47 +296,47 @@ class SlabGroup:
         self.iterations = iterations
 
     def _halo(self, what):
-        outs = [b.halo_pack(what) for b in self.backends]
-        counts = None
-        if isinstance(self.exchange, TorchExchange):
-            counts = list(self.backends[0].gcount)
-        ins = self.exchange.run(outs, self.backends, 4, recv_counts=counts)
+        outs = [tuple([t] for t in b.halo_pack(what)) for b in self.backends]
+        counts = [([b.gcount[0]], [b.gcount[1]]) for b in self.backends]
+        ins = self.exchange.run(outs, self.backends, counts)
         for b, (fl, fr) in zip(self.backends, ins):
-            b.halo_unpack(what, fl, fr)
+            b.halo_unpack(what, fl[0], fr[0])
 
     def step(self, dt):
         B = self.backends
         for b in B:
             b.predict(dt)
-        outs = [b.partition() for b in B]
-        ins = self.exchange.run(outs, B, REC)
+            b.split_launch()
+        cn = self.exchange.counts(B)            # the one host synchronisation of the sub-step
+        outs = [b.split_finish(own) for b, (own, _, _) in zip(B, cn)]
+        ins = self.exchange.run(outs, B, [(fl, fr) for (_, fl, fr) in cn])
         for b, (fl, fr) in zip(B, ins):
-            b.append_owned(fl)
-            b.append_owned(fr)
-        outs = [b.pack_ghosts() for b in B]
-        ins = self.exchange.run(outs, B, REC)
-        for b, (fl, fr) in zip(B, ins):
-            b.append_ghosts(fl, 0)
-            b.append_ghosts(fr, 1)
+            b.append_owned(fl[0], fr[0])        # migrants in
+            b.append_ghosts(fl[1], fr[1])       # neighbour planes (+ own migrants out)
         for b in B:
             b.build()
         viscous = B[0].viscous
+        # with a second ghost layer the local sweeps give the inner layer's lambda / omega
+        local_ghost_sweeps = B[0].ghost_layers >= 2
         for it in range(self.iterations):
             for b in B:
                 b.lambda_pass(dt)
-            self._halo(HALO_PRED_LAMBDA)
+            if not local_ghost_sweeps:
+                self._halo(HALO_PRED_LAMBDA)
             for b in B:
                 b.delta_pass(dt)
             if it + 1 < self.iterations or viscous:
                 self._halo(HALO_PRED_LAMBDA)
+        # the velocity update also runs over the ghosts: their old and (refreshed) new positions
+        # are both here, so v = (new - old) / dt needs no exchange
         for b in B:
             b.finalize_stage(0, dt)
         if viscous:
-            self._halo(HALO_VELOCITY)
             if B[0].vorticity:
                 for b in B:
                     b.finalize_stage(1, dt)
-                self._halo(HALO_OMEGA)
+                if not local_ghost_sweeps:
+                    self._halo(HALO_OMEGA)
                 for b in B:
                     b.finalize_stage(2, dt)
                 if B[0].xsph:

@@ -215,22 +215,40 @@ int pbf_finalize_stage(pbf_ctx* ctx, int32_t stage, float dt);
 enum { PBF_HALO_PRED_LAMBDA = 0, PBF_HALO_VELOCITY = 1, PBF_HALO_OMEGA = 2, PBF_HALO_POSITION = 3 };
 /* run this ctx's kernels on the caller's HIP stream (hipStream_t) instead of its own */
 int pbf_set_stream(pbf_ctx* ctx, void* hip_stream);
-/* INT32_MIN / INT32_MAX mark an open end; requires PBF_RHO0_FIXED */
-int pbf_slab_set_bounds(pbf_ctx* ctx, int32_t x_lo, int32_t x_hi);
-/* after pbf_predict: drops last step's ghosts, keeps the particles whose predicted cell is still
- * owned, packs the others into d_left / d_right; counts = {stay, left, right} (synchronises) */
-int pbf_slab_partition(pbf_ctx* ctx, void* d_left, void* d_right, uint32_t max_records,
-                       uint32_t counts[3]);
-/* appends records: ghost_side -1 = owned (migrants, initial population), 0 / 1 = ghosts
- * received from the left / right neighbour (owned first, then ghosts) */
-int pbf_slab_append(pbf_ctx* ctx, const void* d_records, uint32_t count, int32_t ghost_side);
-/* packs the owned particles of the boundary cell plane (side 0: x_lo, side 1: x_hi - 1) for the
- * neighbour on that side and remembers them for the halo refreshes (synchronises) */
-int pbf_slab_pack_ghosts(pbf_ctx* ctx, int32_t side, void* d_out, uint32_t max_records,
-                         uint32_t* count);
+/* INT32_MIN / INT32_MAX mark an open end; requires PBF_RHO0_FIXED.  ghost_layers = number of
+ * boundary cell planes sent to each neighbour: 1 is enough for the neighbour sweeps; with 2 the
+ * ghosts' lambda of a solver iteration is computed locally (bit-identical) and one halo
+ * refresh per iteration is saved */
+int pbf_slab_set_bounds(pbf_ctx* ctx, int32_t x_lo, int32_t x_hi, int32_t ghost_layers);
+/* after pbf_predict, asynchronous, one pass over the slab: drops last step's ghosts; keeps the
+ * particles whose predicted cell is still owned; packs the others as migrant records into
+ * d_mig_left / d_mig_right; packs the stayers of the boundary cell planes ([x_lo, x_lo+L) for the
+ * left neighbour, [x_hi-L, x_hi) for the right one) as ghost records into d_ghost_left /
+ * d_ghost_right and remembers them for the halo refreshes.  d_counts (device, 6 x uint32:
+ * {stay, too_far, mig_left, ghost_left, mig_right, ghost_right}) is written on the ctx stream, so the
+ * caller can forward [2..3] / [4..5] to its neighbours before anyone synchronises.  The migrant
+ * buffers must stay untouched until pbf_slab_append_ghosts has run. */
+int pbf_slab_split(pbf_ctx* ctx, void* d_mig_left, void* d_mig_right, void* d_ghost_left,
+                   void* d_ghost_right, uint32_t max_records, void* d_counts);
+/* host bookkeeping once the caller has read d_counts back (the one host synchronisation of a
+ * sub-step is the caller's).  Fails when a buffer overflowed or when too_far != 0: a particle
+ * left its slab by more than ghost_layers cell planes in one sub-step, which the one-round
+ * exchange (leavers stay behind as ghosts) does not cover. */
+int pbf_slab_split_done(pbf_ctx* ctx, const uint32_t counts[6]);
+/* appends two record buffers as owned particles: the migrants received from the left / right
+ * neighbour (which also join that side's boundary list: their sender keeps them as ghosts), or
+ * the initial population */
+int pbf_slab_append_owned(pbf_ctx* ctx, const void* d_from_left, uint32_t count_left,
+                          const void* d_from_right, uint32_t count_right);
+/* appends the ghost records received from the left / right neighbour, each followed by this
+ * slab's own migrants to that side (re-read from the pbf_slab_split buffers): ghosts of side s =
+ * neighbour's boundary-plane particles ++ particles that just left towards s */
+int pbf_slab_append_ghosts(pbf_ctx* ctx, const void* d_from_left, uint32_t count_left,
+                           const void* d_from_right, uint32_t count_right);
 /* after pbf_build_grid: one float4 per boundary-plane particle / per ghost, in pack order */
-int pbf_slab_pack_halo(pbf_ctx* ctx, int32_t side, int32_t what, void* d_out);
-int pbf_slab_unpack_halo(pbf_ctx* ctx, int32_t side, int32_t what, const void* d_in, uint32_t count);
+int pbf_slab_pack_halo(pbf_ctx* ctx, int32_t what, void* d_left, void* d_right);
+int pbf_slab_unpack_halo(pbf_ctx* ctx, int32_t what, const void* d_from_left, uint32_t count_left,
+                         const void* d_from_right, uint32_t count_right);
 /* all owned particles as records, arbitrary order (synchronises) */
 int pbf_slab_export(pbf_ctx* ctx, void* d_records, uint32_t max_records, uint32_t* count);
 

@@ -19,12 +19,13 @@ from oracle import pyoracle
 
 
 class OracleSlabBackend:
-    def __init__(self, params, colliders, uniform_mass, x_lo, x_hi, threads=2):
+    def __init__(self, params, colliders, uniform_mass, x_lo, x_hi, threads=2, ghost_layers=2):
         self.params = params.copy()
         self.cols = colliders
         self.mass = np.float32(uniform_mass)
         self.x_lo, self.x_hi = x_lo, x_hi
         self.threads = threads
+        self.ghost_layers = ghost_layers
         self.spacing = np.float32(params.grid_spacing)
         e3 = np.zeros((0, 3), np.float32)
         self.ids = np.zeros(0, np.uint32)
@@ -58,41 +59,57 @@ class OracleSlabBackend:
         o.collision_detection(dt)
         _, self.vel, self.pred, _ = o.download()
 
-    def partition(self):
+    def split_launch(self):
         cx = cell_x(self.pred[:, 0], self.spacing)
         left, right = cx < self.x_lo, cx >= self.x_hi
         stay = ~(left | right)
-        out = []
-        for m in (left, right):
-            out.append(self.to_backend(make_records(self.pos[m], self.vel[m], self.pred[m], self.ids[m], self.mass)))
+        rec = lambda m: make_records(self.pos[m], self.vel[m], self.pred[m], self.ids[m], self.mass)
+        self.mig_out = [rec(left), rec(right)]
+        L = self.ghost_layers
+        too_far = int((left & (cx < self.x_lo - L)).sum() + (right & (cx >= self.x_hi + L)).sum())
+        self.gh_out = []
+        for side, lo, hi, open_end in ((0, self.x_lo, self.x_lo + L, self.x_lo <= -(2 ** 31)),
+                                       (1, self.x_hi - L, self.x_hi, self.x_hi >= 2 ** 31 - 1)):
+            m = (stay & (cx >= lo) & (cx < hi)) if not open_end else np.zeros(cx.shape, bool)
+            self.bids[side] = self.ids[m]
+            self.gh_out.append(rec(m))
         self.ids, self.pos, self.vel, self.pred = self.ids[stay], self.pos[stay], self.vel[stay], self.pred[stay]
         self.gid = [np.zeros(0, np.uint32), np.zeros(0, np.uint32)]
         self.gcount = [0, 0]
-        return out[0], out[1]
+        self.counts = torch.tensor([int(stay.sum()), too_far, self.mig_out[0].shape[0], self.gh_out[0].shape[0],
+                                    self.mig_out[1].shape[0], self.gh_out[1].shape[0], 0, 0], dtype=torch.int32)
 
-    def append_owned(self, rec):
-        rec = rec.numpy()
-        if not rec.shape[0]:
-            return
-        self.ids = np.concatenate([self.ids, record_ids(rec)])
-        self.pos = np.concatenate([self.pos, rec[:, 0:3]])
-        self.vel = np.concatenate([self.vel, rec[:, 4:7]])
-        self.pred = np.concatenate([self.pred, rec[:, 8:11]])
+    def count_tensor(self):
+        return self.counts
 
-    def pack_ghosts(self):
-        cx = cell_x(self.pred[:, 0], self.spacing)
-        out = []
-        for side, plane, open_end in ((0, self.x_lo, self.x_lo <= -(2 ** 31)), (1, self.x_hi - 1, self.x_hi >= 2 ** 31 - 1)):
-            m = (cx == plane) if not open_end else np.zeros(cx.shape, bool)
-            self.bids[side] = self.ids[m]
-            out.append(self.to_backend(make_records(self.pos[m], self.vel[m], self.pred[m], self.ids[m], self.mass)))
-        return out[0], out[1]
+    def split_finish(self, own):
+        assert list(own[:6]) == self.counts.tolist()[:6]
+        if own[1]:
+            raise RuntimeError("a particle crossed more than ghost_layers cell planes beyond its slab")
+        self.in_step = True
+        t = self.to_backend
+        return ([t(self.mig_out[0]), t(self.gh_out[0])], [t(self.mig_out[1]), t(self.gh_out[1])])
 
-    def append_ghosts(self, rec, side):
-        rec = rec.numpy()
-        self.grec[side] = rec
-        self.gid[side] = record_ids(rec)
-        self.gcount[side] = rec.shape[0]
+    def append_owned(self, from_left, from_right=None):
+        parts = [from_left.numpy()] + ([from_right.numpy()] if from_right is not None else [])
+        for side, rec in enumerate(parts):
+            if not rec.shape[0]:
+                continue
+            self.ids = np.concatenate([self.ids, record_ids(rec)])
+            self.pos = np.concatenate([self.pos, rec[:, 0:3]])
+            self.vel = np.concatenate([self.vel, rec[:, 4:7]])
+            self.pred = np.concatenate([self.pred, rec[:, 8:11]])
+            if getattr(self, "in_step", False):
+                # the sender keeps its migrants as ghosts: they join this side's boundary list
+                self.bids[side] = np.concatenate([self.bids[side], record_ids(rec)])
+
+    def append_ghosts(self, from_left, from_right):
+        for side, rec in ((0, from_left), (1, from_right)):
+            rec = np.concatenate([rec.numpy(), self.mig_out[side]], axis=0)
+            self.grec[side] = rec
+            self.gid[side] = record_ids(rec)
+            self.gcount[side] = rec.shape[0]
+        self.in_step = False
 
     def build(self):
         g = np.concatenate(self.grec, axis=0) if (self.gcount[0] + self.gcount[1]) else np.zeros((0, REC), np.float32)

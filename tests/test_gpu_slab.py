@@ -16,11 +16,12 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def hip_backend(p, cols, mass, lo, hi):
+def hip_backend(p, cols, mass, lo, hi, ghost_layers=2):
     from fluidsimulation_amd.slab import HipSlabBackend
     q = p.copy()
     q.capacity = max(int(p.capacity), 4096)
-    return HipSlabBackend(q, cols, mass, lo, hi, device=0, max_records=int(q.capacity))
+    return HipSlabBackend(q, cols, mass, lo, hi, device=0, max_records=int(q.capacity),
+                          ghost_layers=ghost_layers)
 
 
 @pytest.mark.parametrize("world", [1, 2, 3])
@@ -38,9 +39,11 @@ def test_hip_slabs_equal_single_domain(world):
     assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
 
 
-def test_hip_slabs_with_viscosity():
-    p, pos, mass, cols, vel = slab_scene(nx=16, iterations=2, xsph_c=0.01, vorticity_eps=0.05, vel_scale=2.0)
-    group, _ = build_local_group(hip_backend, p, pos, mass, cols, vel, 3)
+@pytest.mark.parametrize("layers", [1, 2])
+def test_hip_slabs_with_viscosity(layers):
+    p, pos, mass, cols, vel = slab_scene(nx=16, iterations=2, xsph_c=0.01, vorticity_eps=2e-6, vel_scale=2.0)
+    make = lambda p, cols, mass, lo, hi: hip_backend(p, cols, mass, lo, hi, ghost_layers=layers)
+    group, _ = build_local_group(make, p, pos, mass, cols, vel, 3)
     for _ in range(4):
         group.step(DT)
     ids, gpos, gvel = group.export()
@@ -86,6 +89,15 @@ def test_rank_local_grids_do_not_change_results():
     _, gpos, gvel = group.export()
     opos, ovel = single_domain_oracle(p, pos, mass, cols, vel, steps)
     assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
+
+
+def test_leaver_beyond_the_ghost_planes_is_reported():
+    from fluidsimulation_amd.binding import PbfError
+    p, pos, mass, cols, vel = slab_scene(vel_scale=0.1)
+    vel[np.argmin(pos[:, 0])] = (1000.0, 0.0, 0.0)   # 0.5 m = 12 cells in one sub-step
+    group, _ = build_local_group(hip_backend, p, pos, mass, cols, vel, 2)
+    with pytest.raises(PbfError, match="ghost_layers"):
+        group.step(DT)
 
 
 def test_id_indexed_readback_is_refused_in_slab_mode():

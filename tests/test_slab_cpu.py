@@ -36,14 +36,29 @@ def test_local_slabs_equal_single_domain(world):
     assert (start_owner != end_owner).sum() > 0
 
 
-def test_local_slabs_with_viscosity():
-    p, pos, mass, cols, vel = slab_scene(nx=16, iterations=2, xsph_c=0.01, vorticity_eps=0.05, vel_scale=2.0)
-    group, _ = build_local_group(oracle_backend, p, pos, mass, cols, vel, 3)
+@pytest.mark.parametrize("layers", [1, 2])
+def test_local_slabs_with_viscosity(layers):
+    """one ghost layer: lambda / omega of the ghosts come from their owners; two layers: from
+    the local sweeps -- both must equal the single-domain run"""
+    from oracle.slab_backend import OracleSlabBackend
+    p, pos, mass, cols, vel = slab_scene(nx=16, iterations=2, xsph_c=0.01, vorticity_eps=2e-6, vel_scale=2.0)
+    make = lambda p, cols, mass, lo, hi: OracleSlabBackend(p, cols, mass, lo, hi, ghost_layers=layers)
+    group, _ = build_local_group(make, p, pos, mass, cols, vel, 3)
     for _ in range(4):
         group.step(DT)
     ids, gpos, gvel = group.export()
     opos, ovel = single_domain_oracle(p, pos, mass, cols, vel, 4)
     assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
+
+
+def test_leaver_beyond_the_ghost_planes_is_reported():
+    """the one-round exchange keeps leavers behind as ghosts; a particle that jumps further than
+    the ghost planes in one sub-step must fail loudly, not silently lose neighbours"""
+    p, pos, mass, cols, vel = slab_scene(vel_scale=0.1)
+    vel[np.argmin(pos[:, 0])] = (1000.0, 0.0, 0.0)   # 0.5 m = 12 cells in one sub-step
+    group, _ = build_local_group(oracle_backend, p, pos, mass, cols, vel, 2)
+    with pytest.raises(RuntimeError, match="ghost_layers"):
+        group.step(DT)
 
 
 def _free_port():

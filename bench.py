@@ -183,7 +183,8 @@ def main():
             achieved = ALGO_BYTES[dom] * n_local / per_launch_s / 1e9
             tr = pmc_traffic(dom)
             traffic = None
-            if tr and tr["particles_per_launch"] == n_local:
+            # the PMC summary derives its particle count from SQ_WAVES x 64 (rounded up per block)
+            if tr and abs(tr["particles_per_launch"] - n_local) < 1024:
                 traffic = tr["bytes_per_launch"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

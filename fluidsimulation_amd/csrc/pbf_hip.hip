@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_sqrt(uint32_t first, uint32_
 
 struct StatPartial {
     double sum_abs_C, sum_C, max_abs_C, msum, mx, my, mz, max_speed2;
-    unsigned long long nbr_total;
+    unsigned long long nbr_total, count;   // count = owned (non-ghost) particles seen
     uint32_t nonfinite, max_nbr;
 };
 
@@ -1145,6 +1145,7 @@ __global__ __launch_bounds__(BLOCK) void k_stats(const float4* __restrict__ pos,
     memset(&a, 0, sizeof(a));
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         if (id[i] & 0x80000000u) continue;  // slab ghost
+        a.count++;
         float4 p = pos[i];
         if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {
             a.nonfinite++;
@@ -1179,6 +1180,7 @@ __global__ __launch_bounds__(BLOCK) void k_stats(const float4* __restrict__ pos,
         double s1 = __shfl_down(a.max_speed2, off, 64);
         a.max_speed2 = s1 > a.max_speed2 ? s1 : a.max_speed2;
         a.nbr_total += __shfl_down(a.nbr_total, off, 64);
+        a.count += __shfl_down(a.count, off, 64);
         a.nonfinite += __shfl_down(a.nonfinite, off, 64);
         uint32_t k1 = __shfl_down(a.max_nbr, off, 64);
         a.max_nbr = k1 > a.max_nbr ? k1 : a.max_nbr;
@@ -1198,6 +1200,7 @@ __global__ __launch_bounds__(BLOCK) void k_stats(const float4* __restrict__ pos,
             t.mz += b.mz;
             t.max_speed2 = b.max_speed2 > t.max_speed2 ? b.max_speed2 : t.max_speed2;
             t.nbr_total += b.nbr_total;
+            t.count += b.count;
             t.nonfinite += b.nonfinite;
             t.max_nbr = b.max_nbr > t.max_nbr ? b.max_nbr : t.max_nbr;
         }
@@ -2213,8 +2216,9 @@ int pbf_get_stats(pbf_ctx* c, pbf_stats* out) {
     HIP_CK(c, hipStreamSynchronize(c->stream));
     out->neighbor_overflow = f.neighbor_overflow;
     double sa = 0, sc = 0, mx = 0, ms = 0, cx = 0, cy = 0, cz = 0, v2 = 0;
-    unsigned long long tot = 0;
+    unsigned long long tot = 0, owned = 0;
     for (auto& p : parts) {
+        owned += p.count;
         sa += p.sum_abs_C;
         sc += p.sum_C;
         mx = p.max_abs_C > mx ? p.max_abs_C : mx;
@@ -2227,10 +2231,11 @@ int pbf_get_stats(pbf_ctx* c, pbf_stats* out) {
         out->nonfinite += p.nonfinite;
         out->max_neighbor_count = p.max_nbr > out->max_neighbor_count ? p.max_nbr : out->max_neighbor_count;
     }
-    if (c->n) {
-        out->mean_abs_C = sa / c->n;
-        out->mean_C = sc / c->n;
-        out->mean_neighbor_count = (double)tot / c->n;
+    out->n = (uint32_t)owned;   // slab mode: ghosts are not counted
+    if (owned) {
+        out->mean_abs_C = sa / owned;
+        out->mean_C = sc / owned;
+        out->mean_neighbor_count = (double)tot / owned;
     }
     out->max_abs_C = mx;
     if (ms > 0) {

@@ -68,6 +68,24 @@ def split_planes(pos, spacing, world, min_width=2 * GHOST_LAYERS):
     return planes
 
 
+def shift_planes(planes, counts, tolerance=0.05, min_width=2 * GHOST_LAYERS):
+    """Incremental re-balancing: every interior plane moves by at most ONE cell
+    towards the heavier of its two slabs (so that, together with the < 1 cell a particle moves
+    per sub-step, a leaver still lands inside the ghost planes: the one-round exchange holds).
+    Pure function of data every rank has -> all ranks take the same decision."""
+    new = list(planes)
+    world = len(planes) - 1
+    for r in range(1, world):
+        a, b = counts[r - 1], counts[r]
+        left_lo = new[r - 1]                       # already final for this sweep
+        right_hi = planes[r + 1]
+        if a > b * (1.0 + tolerance) and (left_lo == INT32_MIN or planes[r] - 1 - left_lo >= min_width):
+            new[r] = planes[r] - 1
+        elif b > a * (1.0 + tolerance) and (right_hi == INT32_MAX or right_hi - (planes[r] + 1) >= min_width + 1):
+            new[r] = planes[r] + 1
+    return new
+
+
 def make_records(pos, vel, pred, ids, mass):
     n = pos.shape[0]
     rec = np.zeros((n, REC), np.float32)
@@ -157,6 +175,13 @@ class HipSlabBackend:
         self.ctx.slab_append_ghosts(l.data_ptr() if l.shape[0] else 0, l.shape[0],
                                     r.data_ptr() if r.shape[0] else 0, r.shape[0])
         self.in_step = False
+
+    def set_bounds(self, x_lo, x_hi):
+        self.ctx.slab_set_bounds(x_lo, x_hi, self.ghost_layers)
+
+    def owned_count(self):
+        """owned particles after the last sub-step (ghosts sit behind them until the next split)"""
+        return int(self.ctx.n) - self.gcount[0] - self.gcount[1]
 
     def build(self):
         self.ctx.build_grid()
@@ -345,6 +370,17 @@ class SlabGroup:
                 for b in B:
                     b.finalize_stage(3, dt)
 
+    def rebalance(self, planes, counts, tolerance=0.05):
+        """Moves the slab planes one cell towards balance (call between sub-steps, with the
+        owned counts of ALL slabs); the next split migrates the particles of the moved plane.
+        Returns the new planes."""
+        new = shift_planes(planes, counts, tolerance)
+        if new != list(planes):
+            first = getattr(self.exchange, "rank", 0)
+            for k, b in enumerate(self.backends):
+                b.set_bounds(new[first + k], new[first + k + 1])
+        return new
+
     def export(self):
         """(ids, pos, vel) of every locally owned particle, sorted by id."""
         recs = [b.export() for b in self.backends]
@@ -393,7 +429,7 @@ class SlabSimulation:
     """What bench.py and multi-GPU callers use: this rank's slab of a scene, over RCCL."""
 
     def __init__(self, params: PbfParams, pos, mass, colliders, rank, world, device=0, vel=None,
-                 headroom=1.5):
+                 headroom=1.5, rebalance_every=0):
         import torch.distributed as dist
         planes = split_planes(pos, params.grid_spacing, world)
         self.planes = planes
@@ -405,9 +441,49 @@ class SlabSimulation:
         self.group = SlabGroup([self.backend], TorchExchange(rank, world), int(params.solver_iterations))
         self.ctx = self.backend.ctx
         self.dist = dist
+        self.rank, self.world = rank, world
+        self.steps = 0
+        self.rebalance_every = rebalance_every
 
     def step(self, dt):
         self.group.step(dt)
+        self.steps += 1
+        if self.rebalance_every and self.steps % self.rebalance_every == 0:
+            self.rebalance()
+
+    def owned_counts(self):
+        """owned particles of every rank (all-gather of one integer)"""
+        import torch
+        dev = self.backend.device if self.group.exchange.on_gpu else torch.device("cpu")
+        mine = torch.tensor([self.backend.owned_count()], dtype=torch.int64, device=dev)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [int(t.item()) for t in out]
+
+    def rebalance(self, tolerance=0.05):
+        self.planes = self.group.rebalance(self.planes, self.owned_counts(), tolerance)
+
+    def stats(self):
+        """Whole-scene health figures: the per-rank pbf_get_stats (owned particles only) combined
+        with two small all-reduces (sum and max), SURVEY.md 8(e)."""
+        import torch
+        st = self.ctx.stats()
+        dev = self.backend.device if self.group.exchange.on_gpu else torch.device("cpu")
+        n = float(st.n)
+        sums = torch.tensor([n, st.nonfinite, st.neighbor_overflow, n * st.mean_neighbor_count,
+                             n * st.mean_abs_C, n * st.mean_C, n * st.com[0], n * st.com[1],
+                             n * st.com[2]], dtype=torch.float64, device=dev)
+        maxs = torch.tensor([st.max_neighbor_count, st.max_abs_C, st.max_speed],
+                            dtype=torch.float64, device=dev)
+        self.dist.all_reduce(sums, op=self.dist.ReduceOp.SUM)
+        self.dist.all_reduce(maxs, op=self.dist.ReduceOp.MAX)
+        sums, maxs = sums.tolist(), maxs.tolist()
+        tot = max(sums[0], 1.0)
+        return {"n": int(sums[0]), "nonfinite": int(sums[1]), "neighbor_overflow": int(sums[2]),
+                "mean_neighbor_count": sums[3] / tot, "mean_abs_C": sums[4] / tot,
+                "mean_C": sums[5] / tot, "com": [sums[6] / tot, sums[7] / tot, sums[8] / tot],
+                "max_neighbor_count": int(maxs[0]), "max_abs_C": maxs[1], "max_speed": maxs[2],
+                "rest_density": st.rest_density}
 
     def sync(self):
         self.backend.sync()

@@ -111,6 +111,12 @@ class OracleSlabBackend:
             self.gcount[side] = rec.shape[0]
         self.in_step = False
 
+    def set_bounds(self, x_lo, x_hi):
+        self.x_lo, self.x_hi = x_lo, x_hi
+
+    def owned_count(self):
+        return int(self.ids.shape[0])
+
     def build(self):
         g = np.concatenate(self.grec, axis=0) if (self.gcount[0] + self.gcount[1]) else np.zeros((0, REC), np.float32)
         gids = np.concatenate(self.gid)

@@ -91,6 +91,21 @@ def test_rank_local_grids_do_not_change_results():
     assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
 
 
+def test_rebalancing_between_substeps_keeps_the_result():
+    p, pos, mass, cols, vel = slab_scene(nx=28)
+    steps = 6
+    group, planes = build_local_group(hip_backend, p, pos, mass, cols, vel, 3)
+    seen = {tuple(planes)}
+    for _ in range(steps):
+        group.step(DT)
+        planes = group.rebalance(planes, [b.owned_count() for b in group.backends], tolerance=0.0)
+        seen.add(tuple(planes))
+    assert len(seen) > 1
+    ids, gpos, gvel = group.export()
+    opos, ovel = single_domain_oracle(p, pos, mass, cols, vel, steps)
+    assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
+
+
 def test_leaver_beyond_the_ghost_planes_is_reported():
     from fluidsimulation_amd.binding import PbfError
     p, pos, mass, cols, vel = slab_scene(vel_scale=0.1)
@@ -119,22 +134,20 @@ def _free_port():
 def _worker(rank, world, port, steps, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, str(ROOT))
+    import json
     import torch.distributed as dist
-    from fluidsimulation_amd.slab import (SlabGroup, TorchExchange, populate, rank_local_params,
-                                          split_planes)
+    from fluidsimulation_amd.slab import SlabSimulation
     dist.init_process_group("gloo", rank=rank, world_size=world)
     p, pos, mass, cols, vel = slab_scene()
-    planes = split_planes(pos, p.grid_spacing, world)
-    # the rank-local grid SlabSimulation (bench.py --gpus N) uses
-    b = hip_backend(rank_local_params(p, pos, planes, rank, world), cols, mass, planes[rank], planes[rank + 1])
-    populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
-             p.grid_spacing, vel=vel)
-    g = SlabGroup([b], TorchExchange(rank, world), int(p.solver_iterations))
+    # exactly what bench.py --gpus N builds (rank-local grid, TorchExchange), plus re-balancing
+    sim = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=0, vel=vel, rebalance_every=2)
     for _ in range(steps):
-        g.step(DT)
-    b.sync()
-    ids, gpos, gvel = g.export()
+        sim.step(DT)
+    sim.sync()
+    st = sim.stats()
+    ids, gpos, gvel = sim.export()
     np.savez(Path(out_dir) / f"rank{rank}.npz", ids=ids, pos=gpos, vel=gvel)
+    (Path(out_dir) / f"stats{rank}.json").write_text(json.dumps({"stats": st, "planes": sim.planes}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -153,3 +166,9 @@ def test_two_processes_one_gpu_over_gloo(tmp_path):
     p, pos, mass, cols, vel = slab_scene()
     opos, ovel = single_domain_oracle(p, pos, mass, cols, vel, steps)
     assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
+    # the all-reduced health figures are the same on both ranks and cover the whole scene
+    import json
+    st = [json.loads((tmp_path / f"stats{r}.json").read_text()) for r in range(world)]
+    assert st[0] == st[1]
+    assert st[0]["stats"]["n"] == pos.shape[0] and st[0]["stats"]["nonfinite"] == 0
+    np.testing.assert_allclose(st[0]["stats"]["com"], opos.astype(np.float64).mean(axis=0), rtol=1e-6)

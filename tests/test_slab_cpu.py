@@ -51,6 +51,35 @@ def test_local_slabs_with_viscosity(layers):
     assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
 
 
+def test_shift_planes_moves_one_cell_towards_balance():
+    from fluidsimulation_amd.slab import INT32_MAX, INT32_MIN, shift_planes
+    planes = [INT32_MIN, 10, 20, INT32_MAX]
+    assert shift_planes(planes, [100, 100, 100]) == planes
+    assert shift_planes(planes, [200, 100, 100]) == [INT32_MIN, 9, 20, INT32_MAX]
+    assert shift_planes(planes, [100, 100, 300]) == [INT32_MIN, 10, 21, INT32_MAX]
+    assert shift_planes(planes, [100, 300, 100]) == [INT32_MIN, 11, 19, INT32_MAX]
+    # a slab never gets thinner than the ghost planes need
+    assert shift_planes([INT32_MIN, 10, 14, INT32_MAX], [100, 300, 100]) == [INT32_MIN, 10, 14, INT32_MAX]
+    assert shift_planes([INT32_MIN, 10, 15, INT32_MAX], [100, 300, 100]) == [INT32_MIN, 10, 14, INT32_MAX]
+
+
+def test_rebalancing_between_substeps_keeps_the_result():
+    """planes move one cell per sub-step (tolerance 0 forces a move whenever counts differ);
+    the slab run must still equal the single-domain run bit for bit"""
+    p, pos, mass, cols, vel = slab_scene(nx=28)
+    steps = 6
+    group, planes = build_local_group(oracle_backend, p, pos, mass, cols, vel, 3)
+    seen = {tuple(planes)}
+    for _ in range(steps):
+        group.step(DT)
+        planes = group.rebalance(planes, [b.owned_count() for b in group.backends], tolerance=0.0)
+        seen.add(tuple(planes))
+    assert len(seen) > 1
+    ids, gpos, gvel = group.export()
+    opos, ovel = single_domain_oracle(p, pos, mass, cols, vel, steps)
+    assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
+
+
 def test_leaver_beyond_the_ghost_planes_is_reported():
     """the one-round exchange keeps leavers behind as ghosts; a particle that jumps further than
     the ghost planes in one sub-step must fail loudly, not silently lose neighbours"""

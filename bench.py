@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2, help="oracle sub-steps to time (0 = skip)")
     ap.add_argument("--cpu-block", type=int, nargs=3, default=None)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path with several ranks sharing one GPU "
+                         "(payloads staged through the host); numbers from it are not bench results")
     return ap.parse_args()
 
 
@@ -104,9 +107,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the PBF path has no CPU fallback")
+    if a.backend == "gloo":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     from fluidsimulation_amd import PbfContext, scenes
     from fluidsimulation_amd import binding as B
@@ -152,11 +160,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    stats = ctx.stats()
+    # health figures of the whole scene (N>1: per-rank stats combined by two small all-reduces)
+    stats = ctx.stats().as_dict() if world == 1 else sim.stats()
 
     # per-kernel device time with HIP events on the ctx stream (a second pass: the event
     # records sit between launches, so this pass is not the one `value` comes from)
@@ -211,7 +220,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if a.backend == "nccl" else "synthetic (REHEARSAL over gloo: not a bench result)",
             "config": {"workload": workload, "particles": n_total, "iterations": a.iters,
                        "arithmetic": "f32 state and accumulation, f64 SPH-kernel evaluation (as the reference CPU path)", "parallelism": parallelism,
                        "substeps_per_s": a.steps / elapsed},
@@ -219,9 +228,9 @@ def main():
             "roofline": roofline,
             "phases": phases,
             "cpu_baseline": cpu,
-            "health": {"nonfinite": stats.nonfinite, "neighbor_overflow": stats.neighbor_overflow,
-                       "max_neighbors": stats.max_neighbor_count,
-                       "mean_neighbors": stats.mean_neighbor_count, "mean_abs_C": stats.mean_abs_C},
+            "health": {"nonfinite": stats["nonfinite"], "neighbor_overflow": stats["neighbor_overflow"],
+                       "max_neighbors": stats["max_neighbor_count"],
+                       "mean_neighbors": stats["mean_neighbor_count"], "mean_abs_C": stats["mean_abs_C"]},
         }
         print(json.dumps(out))
     if world > 1:

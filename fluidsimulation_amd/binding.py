@@ -153,6 +153,7 @@ SYMBOLS = [
     "pbf_get_neighbors", "pbf_get_stats", "pbf_get_rest_density", "pbf_num_particles",
     "pbf_profile_enable", "pbf_profile_reset", "pbf_profile_read", "pbf_num_phases",
     "pbf_phase_name", "pbf_solve_lambda", "pbf_solve_delta", "pbf_finalize_stage", "pbf_set_stream",
+    "pbf_export_positions", "pbf_snapshot_save", "pbf_snapshot_load",
     "pbf_slab_set_bounds", "pbf_slab_split", "pbf_slab_split_done", "pbf_slab_append_owned",
     "pbf_slab_append_ghosts",
     "pbf_slab_pack_halo", "pbf_slab_unpack_halo", "pbf_slab_export", "pbf_selftest_sqrt",
@@ -218,6 +219,9 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_solve_delta.argtypes = [vp, C.c_float]
     lib.pbf_finalize_stage.argtypes = [vp, C.c_int32, C.c_float]
     lib.pbf_set_stream.argtypes = [vp, vp]
+    lib.pbf_export_positions.argtypes = [vp, vp]
+    lib.pbf_snapshot_save.argtypes = [vp, C.c_char_p]
+    lib.pbf_snapshot_load.argtypes = [vp, C.c_char_p]
     lib.pbf_slab_set_bounds.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
     lib.pbf_slab_split.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp]
     lib.pbf_slab_split_done.argtypes = [vp, C.POINTER(C.c_uint32 * 6)]
@@ -369,6 +373,17 @@ class PbfContext:
 
     def set_stream(self, stream_handle: int):
         self._ck(self.lib.pbf_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def export_positions(self, d_xyz: int):
+        """N packed float3 in particle-index order into device memory (asynchronous)"""
+        self._ck(self.lib.pbf_export_positions(self._h, C.c_void_p(d_xyz)))
+
+    def snapshot_save(self, path):
+        self._ck(self.lib.pbf_snapshot_save(self._h, str(path).encode()))
+
+    def snapshot_load(self, path):
+        self._ck(self.lib.pbf_snapshot_load(self._h, str(path).encode()))
+        self.n = int(self.lib.pbf_num_particles(self._h))
 
     def slab_set_bounds(self, x_lo: int, x_hi: int, ghost_layers: int = 2):
         self._ck(self.lib.pbf_slab_set_bounds(self._h, x_lo, x_hi, ghost_layers))

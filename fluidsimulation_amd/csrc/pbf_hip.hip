@@ -96,6 +96,15 @@ __global__ void k_unpack3(const float4* __restrict__ a, const uint32_t* __restri
     out3[o + 2] = v.z;
 }
 
+// mass (pos.w) back to original-id order
+__global__ void k_unpack_w(const float4* __restrict__ a, const uint32_t* __restrict__ id, uint32_t n,
+                           float* __restrict__ out) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (id[i] & 0x80000000u) return;  // slab ghost
+    out[id[i]] = a[i].w;
+}
+
 __global__ void k_unpack_scalars(const float* __restrict__ dens, const float* __restrict__ C,
                                  const float4* __restrict__ prd, const uint32_t* __restrict__ id,
                                  uint32_t n, float* __restrict__ o_dens, float* __restrict__ o_C,
@@ -2244,6 +2253,96 @@ int pbf_get_stats(pbf_ctx* c, pbf_stats* out) {
         out->com[2] = cz / ms;
     }
     out->max_speed = sqrt(v2);
+    return PBF_OK;
+}
+
+int pbf_export_positions(pbf_ctx* c, void* d_xyz) {
+    ENTER(c);
+    if (c->slab) return fail(c, PBF_ERR_INVALID, "id-indexed read-back is not available in slab mode (ids are global): use pbf_slab_export");
+    if (!c->n) return PBF_OK;
+    if (!d_xyz) return fail(c, PBF_ERR_INVALID, "null output");
+    k_unpack3<<<nblocks(c->n), BLOCK, 0, c->stream>>>(c->pos[c->cur], c->id[c->cur], c->n, (float*)d_xyz);
+    LAUNCH_CK(c);
+    return PBF_OK;
+}
+
+// snapshot file: SnapHeader, pos[n][3], vel[n][3], then mass[n] unless uniform; all in
+// particle-index order, little-endian fp32
+struct SnapHeader {
+    char magic[8];          // "PBFSNAP1"
+    uint32_t n;
+    uint32_t flags;         // bit 0: first frame still pending, bit 1: per-particle mass follows
+    float rest_density;     // the device value (fixed, or the first-frame mean once computed)
+    float uniform_mass;
+    uint32_t reserved[10];
+};
+static_assert(sizeof(SnapHeader) == 64, "snapshot header is 64 bytes");
+
+int pbf_snapshot_save(pbf_ctx* c, const char* path) {
+    ENTER(c);
+    if (c->slab) return fail(c, PBF_ERR_INVALID, "snapshots are per ctx in particle-index order: not available in slab mode, use pbf_slab_export");
+    if (!path) return fail(c, PBF_ERR_INVALID, "null path");
+    SnapHeader hd;
+    memset(&hd, 0, sizeof(hd));
+    memcpy(hd.magic, "PBFSNAP1", 8);
+    hd.n = c->n;
+    hd.flags = (c->first_frame ? 1u : 0u) | (c->uniform ? 0u : 2u);
+    hd.uniform_mass = c->uniform_mass;
+    HIP_CK(c, hipMemcpyAsync(&hd.rest_density, c->rho0, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    std::vector<float> buf((size_t)c->n * 3);
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(c, PBF_ERR_INVALID, "cannot open snapshot file for writing");
+    int rc = PBF_OK;
+    bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1;
+    const float4* arrays[2] = {c->pos[c->cur], c->vel[c->cur]};
+    for (int a = 0; a < 2 && ok && rc == PBF_OK; ++a) {
+        rc = download3(c, arrays[a], buf.data());
+        if (rc == PBF_OK && c->n) ok = fwrite(buf.data(), 12, c->n, f) == c->n;
+    }
+    if (rc == PBF_OK && ok && !c->uniform && c->n) {
+        float* st = (float*)c->staging;
+        k_unpack_w<<<nblocks(c->n), BLOCK, 0, c->stream>>>(c->pos[c->cur], c->id[c->cur], c->n, st);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(buf.data(), st, (size_t)c->n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            rc = fail(c, PBF_ERR_HIP, "snapshot: mass read-back failed");
+        else
+            ok = fwrite(buf.data(), 4, c->n, f) == c->n;
+    }
+    if (fclose(f) != 0) ok = false;
+    if (rc != PBF_OK) return rc;
+    if (!ok) return fail(c, PBF_ERR_INVALID, "short write to snapshot file");
+    return PBF_OK;
+}
+
+int pbf_snapshot_load(pbf_ctx* c, const char* path) {
+    ENTER(c);
+    if (c->slab) return fail(c, PBF_ERR_INVALID, "snapshots are not available in slab mode");
+    if (!path) return fail(c, PBF_ERR_INVALID, "null path");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(c, PBF_ERR_INVALID, "cannot open snapshot file");
+    SnapHeader hd;
+    if (fread(&hd, sizeof(hd), 1, f) != 1 || memcmp(hd.magic, "PBFSNAP1", 8) != 0) {
+        fclose(f);
+        return fail(c, PBF_ERR_INVALID, "not a PBFSNAP1 file");
+    }
+    if (hd.n > c->cap) {
+        fclose(f);
+        return fail(c, PBF_ERR_CAPACITY, "snapshot holds more particles than the ctx capacity");
+    }
+    const bool per_particle = hd.flags & 2u;
+    std::vector<float> pos((size_t)hd.n * 3), vel((size_t)hd.n * 3), mass(per_particle ? hd.n : 0);
+    bool ok = fread(pos.data(), 12, hd.n, f) == hd.n && fread(vel.data(), 12, hd.n, f) == hd.n;
+    if (ok && per_particle) ok = fread(mass.data(), 4, hd.n, f) == hd.n;
+    fclose(f);
+    if (!ok) return fail(c, PBF_ERR_INVALID, "truncated snapshot file");
+    int rc = pbf_upload(c, pos.data(), vel.data(), per_particle ? mass.data() : nullptr,
+                        hd.uniform_mass, hd.n);
+    if (rc != PBF_OK) return rc;
+    // resume where the run stopped: the rest density in force and whether frame 1 is done
+    HIP_CK(c, hipMemcpyAsync(c->rho0, &hd.rest_density, 4, hipMemcpyHostToDevice, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    c->first_frame = hd.flags & 1u;
     return PBF_OK;
 }
 

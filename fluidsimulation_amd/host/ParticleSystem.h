@@ -26,6 +26,29 @@ public:
     // replaces Update()/UpdateGLBUfferData (ParticleSystem.cpp:38-49,372-406): instead of
     // re-uploading positions to a GL buffer, refreshes the HOST vectors from the device.
     bool Update();
+    // the reference's VBO contents (ParticleSystem.cpp:372-389, drawn by Renderer.cpp:121-127):
+    // m_size tightly packed float3 positions in particle-index order, written on the device
+    // into caller-owned device memory (e.g. the mapped GL buffer of RegisterCUDAVBO's
+    // counterpart), asynchronous on the ctx stream.
+    bool UpdateDeviceVBO(void* d_xyz) {
+        if (!m_ctx) return false;
+        if (pbf_export_positions(m_ctx, d_xyz) == PBF_OK) return true;
+        m_error = pbf_last_error(m_ctx);
+        return false;
+    }
+    // raw SoA snapshot / restart (include/pbf.h: pbf_snapshot_save/load)
+    bool SaveSnapshot(const char* path) {
+        if (!m_ctx) return false;
+        if (pbf_snapshot_save(m_ctx, path) == PBF_OK) return true;
+        m_error = pbf_last_error(m_ctx);
+        return false;
+    }
+    bool LoadSnapshot(const char* path) {
+        if (!m_ctx) return false;
+        if (pbf_snapshot_load(m_ctx, path) == PBF_OK) return true;
+        m_error = pbf_last_error(m_ctx);
+        return false;
+    }
     void Release();  // ParticleSystem.cpp:59-97
 
     pbf_ctx* context() { return m_ctx; }

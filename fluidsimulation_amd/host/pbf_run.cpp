@@ -2,6 +2,7 @@
 // reference (main.cpp:9-35, GLFWApp.cpp:177-216,383-398), minus the window, renderer and GUI.
 //
 //   pbf_run [--scene c1] [--dims nx ny nz] [--steps N] [--iters K] [--dump file.bin]
+//           [--resume snap.pbf] [--save snap.pbf]   (PBFSNAP1 restart files, include/pbf.h)
 //
 // Builds the reference's lattice scene (GLFWApp::GenerateFluidParticles, GLFWApp.cpp:437-465),
 // adds its five plane colliders, steps with dt = 0.0005, prints stats, and optionally dumps
@@ -17,13 +18,15 @@
 
 int main(int argc, char** argv) {
     int nx = 10, ny = 100, nz = 10, steps = 10, iters = 2;
-    std::string dump;
+    std::string dump, save, resume;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--dims" && i + 3 < argc) { nx = atoi(argv[++i]); ny = atoi(argv[++i]); nz = atoi(argv[++i]); }
         else if (a == "--steps" && i + 1 < argc) steps = atoi(argv[++i]);
         else if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
         else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
+        else if (a == "--save" && i + 1 < argc) save = argv[++i];
+        else if (a == "--resume" && i + 1 < argc) resume = argv[++i];
         else if (a == "--scene" && i + 1 < argc) ++i;  // only c1 here
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -55,6 +58,10 @@ int main(int argc, char** argv) {
         return 1;
     }
     simulator->SetSolverIteration((uint32_t)iters);  // GLFWApp.cpp:216
+    if (!resume.empty() && !particle_system->LoadSnapshot(resume.c_str())) {
+        fprintf(stderr, "LoadSnapshot failed: %s\n", particle_system->error().c_str());
+        return 1;
+    }
     if (!simulator->Step(0.0005f) || !simulator->isPause()) { fprintf(stderr, "pause contract broken\n"); return 1; }
     simulator->Pause();  // the SPACE key, GLFWApp.cpp:285-290
 
@@ -62,6 +69,10 @@ int main(int argc, char** argv) {
     auto t0 = std::chrono::steady_clock::now();
     for (int s = 0; s < steps; ++s)
         if (!simulator->Step(time_step)) { fprintf(stderr, "Step failed: %s\n", simulator->error().c_str()); return 1; }
+    if (!save.empty() && !particle_system->SaveSnapshot(save.c_str())) {
+        fprintf(stderr, "SaveSnapshot failed: %s\n", particle_system->error().c_str());
+        return 1;
+    }
     if (!particle_system->Update()) { fprintf(stderr, "Update failed: %s\n", particle_system->error().c_str()); return 1; }
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 

@@ -206,6 +206,20 @@ int pbf_solve_lambda(pbf_ctx* ctx, float dt);
 int pbf_solve_delta(pbf_ctx* ctx, float dt);
 int pbf_finalize_stage(pbf_ctx* ctx, int32_t stage, float dt);
 
+/* ---- render / export hand-off ------------------------------------
+ * pbf_export_positions: what ParticleSystem::UpdateGLBUfferData uploads and Renderer::
+ * RenderParticles draws (ParticleSystem.cpp:372-389, Renderer.cpp:121-127) and what the
+ * reference's StepCUDA writes through the mapped VBO (Simulation.cpp:160-168): N tightly packed
+ * float3 positions in particle-index order, written into caller-owned DEVICE memory (a mapped
+ * GL buffer, a torch tensor ...) on the ctx stream, asynchronous. */
+int pbf_export_positions(pbf_ctx* ctx, void* d_xyz);
+/* raw SoA snapshot / restart file (no reference counterpart): 64-byte header ("PBFSNAP1", n,
+ * flags, rest density in force, uniform mass), then pos[n][3], vel[n][3] and, with
+ * per-particle masses, mass[n] -- fp32, particle-index order.  A run resumed with
+ * pbf_snapshot_load continues bit-identically (the sorted order is a function of the state). */
+int pbf_snapshot_save(pbf_ctx* ctx, const char* path);
+int pbf_snapshot_load(pbf_ctx* ctx, const char* path);
+
 /* ---- slab decomposition over the GPUs of one node.  No counterpart in the
  * reference, which is single-GPU (cuda_simulation.cu has no multi-device code).  A ctx owns
  * the cells whose x index is in [x_lo, x_hi); neighbours exchange particle records of

@@ -45,3 +45,20 @@ def test_headless_driver_matches_oracle(tmp_path, dims, steps, iters):
     oc, on = o.neighbors()
     assert nb0.tolist() == on[0, :oc[0]].tolist()   # FetchNeighbors(0) in m_search_cache order
     assert f"rest_density {o.rest_density():.9g}" in r.stdout
+
+
+def test_headless_driver_resumes_from_a_snapshot(tmp_path):
+    """3 + 3 sub-steps through a PBFSNAP1 restart file == 6 sub-steps in one go (first-frame rest
+    density travels in the file header)"""
+    dims, iters = (6, 12, 6), 2
+    snap, d1, d2 = tmp_path / "s.pbf", tmp_path / "a.bin", tmp_path / "b.bin"
+    base = [str(RUN), "--dims", *map(str, dims), "--iters", str(iters)]
+    r = subprocess.run(base + ["--steps", "3", "--save", str(snap)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(base + ["--steps", "3", "--resume", str(snap), "--dump", str(d1)], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(base + ["--steps", "6", "--dump", str(d2)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    a, b = read_dump(d1), read_dump(d2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

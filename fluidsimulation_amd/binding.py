@@ -157,6 +157,8 @@ SYMBOLS = [
     "pbf_slab_set_bounds", "pbf_slab_split", "pbf_slab_split_done", "pbf_slab_append_owned",
     "pbf_slab_append_ghosts",
     "pbf_slab_pack_halo", "pbf_slab_unpack_halo", "pbf_slab_export", "pbf_selftest_sqrt",
+    "pbf_set_boundary", "pbf_num_boundary_particles", "pbf_get_boundary",
+    "pbf_get_boundary_neighbors",
 ]
 
 _lib = None
@@ -231,6 +233,11 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_slab_unpack_halo.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp, C.c_uint32]
     lib.pbf_slab_export.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.pbf_selftest_sqrt.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    lib.pbf_set_boundary.argtypes = [vp, vp, vp, C.c_float, C.c_uint32, C.c_uint32]
+    lib.pbf_num_boundary_particles.argtypes = [vp]
+    lib.pbf_num_boundary_particles.restype = C.c_uint32
+    lib.pbf_get_boundary.argtypes = [vp, vp, vp, vp]
+    lib.pbf_get_boundary_neighbors.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32]
     if path is None:
         _lib = lib
     return lib
@@ -289,6 +296,31 @@ class PbfContext:
 
     def set_solver_iterations(self, it: int):
         self._ck(self.lib.pbf_set_solver_iterations(self._h, it))
+
+    def set_boundary(self, pos, mass=None, uniform_mass: float = 1.0, max_boundary_neighbors: int = 0):
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+        nb = pos.shape[0]
+        mass = None if mass is None else np.ascontiguousarray(mass, dtype=np.float32).reshape(nb)
+        self._ck(self.lib.pbf_set_boundary(self._h, _ptr(pos), _ptr(mass), C.c_float(uniform_mass),
+                                           nb, max_boundary_neighbors))
+        self.nb = nb
+        self.kb = max_boundary_neighbors or int(self.params.max_neighbors)
+
+    def boundary(self):
+        """(volume, density, lambda) of the boundary particles, boundary index order"""
+        out = [np.zeros(self.nb, np.float32) for _ in range(3)]
+        self._ck(self.lib.pbf_get_boundary(self._h, *[_ptr(a) for a in out]))
+        return tuple(out)
+
+    def boundary_neighbors(self, stride_f=None, stride_b=None):
+        """(fluid counts, fluid->boundary rows, boundary counts, boundary->fluid rows)"""
+        stride_f = stride_f or self.kb
+        stride_b = stride_b or self.kb
+        fc, fl = np.zeros(self.n, np.uint32), np.zeros((self.n, stride_f), np.uint32)
+        bc, bl = np.zeros(self.nb, np.uint32), np.zeros((self.nb, stride_b), np.uint32)
+        self._ck(self.lib.pbf_get_boundary_neighbors(self._h, _ptr(fc), _ptr(fl), stride_f,
+                                                     _ptr(bc), _ptr(bl), stride_b))
+        return fc, fl, bc, bl
 
     def set_gravity(self, gx, gy, gz):
         self._ck(self.lib.pbf_set_gravity(self._h, gx, gy, gz))

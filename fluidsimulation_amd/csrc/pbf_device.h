@@ -155,13 +155,16 @@ __device__ __forceinline__ float scorr_strict(const KernConsts& k, float w) {
 // called in row order (the summation order of the reference, Simulation.cpp:628,660,692).
 // Row loads stay predicated on k < cnt: loading them unconditionally (measured) costs more in
 // extra row traffic than the removed branches save.
+// `dummy` is the index gathered for the masked-off tail of the last batch: any valid index of x
+// (i itself when the row points into the particle's own set).
 template <int BATCH, typename F>
 __device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t cnt,
                                                   const uint32_t* __restrict__ nbr, uint32_t cap,
-                                                  const float4* __restrict__ x, F&& f) {
+                                                  const float4* __restrict__ x, uint32_t dummy,
+                                                  F&& f) {
     uint32_t jn[BATCH];
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) jn[u] = (uint32_t)u < cnt ? nbr[(size_t)u * cap + i] : i;
+    for (int u = 0; u < BATCH; ++u) jn[u] = (uint32_t)u < cnt ? nbr[(size_t)u * cap + i] : dummy;
     for (uint32_t k0 = 0; k0 < cnt; k0 += BATCH) {
         uint32_t j[BATCH];
         float4 xj[BATCH];
@@ -173,12 +176,19 @@ __device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t cnt,
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
             const uint32_t k = k0 + BATCH + u;
-            jn[u] = k < cnt ? nbr[(size_t)k * cap + i] : i;
+            jn[u] = k < cnt ? nbr[(size_t)k * cap + i] : dummy;
         }
 #pragma unroll
         for (int u = 0; u < BATCH; ++u)
             if (k0 + u < cnt) f(j[u], xj[u]);
     }
+}
+
+template <int BATCH, typename F>
+__device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t cnt,
+                                                  const uint32_t* __restrict__ nbr, uint32_t cap,
+                                                  const float4* __restrict__ x, F&& f) {
+    for_each_neighbor<BATCH>(i, cnt, nbr, cap, x, i, static_cast<F&&>(f));
 }
 
 }  // namespace pbf

@@ -437,7 +437,12 @@ __global__ __launch_bounds__(BLOCK) void k_reorder(
 // x outermost, z innermost, bucket order inside a cell, j != i, dist2 <= h*h (inclusive).
 // Cells are z-fastest in the key, so the visiting order equals the reference's.
 
-__device__ __forceinline__ void neighbors_global_path(uint32_t i, const float4* __restrict__ prd,
+// Query particles q[0..n) and target particles t (cell_start is the TARGET set's) may be
+// different sets sorted on the same grid (fluid <-> boundary particles); SELF = same set, the
+// particle itself is left out.
+template <bool SELF>
+__device__ __forceinline__ void neighbors_global_path(uint32_t i, const float4* __restrict__ q,
+                                                     const float4* __restrict__ prd,
                                                      const uint32_t* __restrict__ cell_start,
                                                      uint32_t n, uint32_t cap, uint32_t K,
                                                      GridConsts G, float square_h,
@@ -445,7 +450,7 @@ __device__ __forceinline__ void neighbors_global_path(uint32_t i, const float4* 
                                                      uint32_t* __restrict__ nbr_count,
                                                      DevFlags* __restrict__ flags) {
     if (i >= n) return;
-    const float4 xi = prd[i];
+    const float4 xi = q[i];
     const int32_t cx = floor_cell(xi.x, G.spacing), cy = floor_cell(xi.y, G.spacing),
                   cz = floor_cell(xi.z, G.spacing);
     const uint32_t wz = (uint32_t)wrap(cz - G.oz, G.gz);
@@ -482,8 +487,10 @@ __device__ __forceinline__ void neighbors_global_path(uint32_t i, const float4* 
             }
             // drop the clamped tail duplicates and the particle itself (p_j == i, :216)
             if (len < 32u) mask &= (1u << len) - 1u;
-            const uint32_t self = i - s;  // wraps to a huge value when i < s
-            if (self < 32u) mask &= ~(1u << self);
+            if (SELF) {
+                const uint32_t self = i - s;  // wraps to a huge value when i < s
+                if (self < 32u) mask &= ~(1u << self);
+            }
             while (mask) {
                 const uint32_t k = (uint32_t)__builtin_ctz(mask);
                 mask &= mask - 1u;
@@ -530,7 +537,9 @@ __device__ __forceinline__ void neighbors_global_path(uint32_t i, const float4* 
 // where keys wrap, or whose ranges exceed the LDS budget).
 constexpr uint32_t NB_LDS_T = 3072;   // staged candidates per workgroup (36 KB as SoA fp32)
 
-__global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ prd,
+template <bool SELF>
+__global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ q,
+                                                     const float4* __restrict__ prd,
                                                      const uint32_t* __restrict__ cell_start,
                                                      uint32_t n, uint32_t cap, uint32_t K,
                                                      GridConsts G, float square_h,
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ 
     uint32_t key = 0;
     bool interior = true;
     if (active) {
-        xi = prd[i];
+        xi = q[i];
         const uint32_t wx = (uint32_t)wrap(floor_cell(xi.x, G.spacing) - G.ox, G.gx);
         const uint32_t wy = (uint32_t)wrap(floor_cell(xi.y, G.spacing) - G.oy, G.gy);
         const uint32_t wz = (uint32_t)wrap(floor_cell(xi.z, G.spacing) - G.oz, G.gz);
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ 
         lds_path = sOk != 0;
     }
     if (!lds_path) {
-        neighbors_global_path(i, prd, cell_start, n, cap, K, G, square_h, nbr, nbr_count, flags);
+        neighbors_global_path<SELF>(i, q, prd, cell_start, n, cap, K, G, square_h, nbr, nbr_count, flags);
         return;
     }
     // stage the nine ranges, coalesced
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ 
     __syncthreads();
     if (!active) return;
     if (!interior) {  // grid-edge cell: its neighbour keys wrap, the staged window does not apply
-        neighbors_global_path(i, prd, cell_start, n, cap, K, G, square_h, nbr, nbr_count, flags);
+        neighbors_global_path<SELF>(i, q, prd, cell_start, n, cap, K, G, square_h, nbr, nbr_count, flags);
         return;
     }
 
@@ -645,7 +654,7 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ 
             }
             if (s < la) mask &= ~((1u << (la - s)) - 1u);           // entries before the range
             if (lb - s < 32u) mask &= (1u << (lb - s)) - 1u;        // entries after it
-            if (r == 4) {                                            // the particle itself (:216)
+            if (SELF && r == 4) {                                    // the particle itself (:216)
                 const uint32_t self = lself - s;
                 if (self < 32u) mask &= ~(1u << self);
             }
@@ -701,7 +710,9 @@ __global__ void k_rest_density_mean(const float* __restrict__ dens_by_id, uint32
 // share one pass over the neighbour row: rho_i and sum_j |gradW/rho0|^2 are independent.
 // lambda is written into prd[i].w (no reader uses .w during this kernel).
 
-template <bool UNIFORM_MASS, int GRAD>
+// BND: boundary-particle terms of pbf_density_boundary / pbf_lambda_boundary
+// (cuda_simulation.cu:665-701,846-884) over the fluid->boundary rows, after the fluid terms.
+template <bool UNIFORM_MASS, int GRAD, bool BND>
 __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __restrict__ pos,
                                                   const uint32_t* __restrict__ nbr,
                                                   const uint32_t* __restrict__ nbr_count,
@@ -709,7 +720,10 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __r
                                                   const float* __restrict__ rho0_ptr,
                                                   float uniform_mass,
                                                   float* __restrict__ dens_out,
-                                                  float* __restrict__ C_out) {
+                                                  float* __restrict__ C_out,
+                                                  const float4* __restrict__ bpos,
+                                                  const uint32_t* __restrict__ fb,
+                                                  const uint32_t* __restrict__ fb_count) {
     uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float rho0 = *rho0_ptr;
@@ -728,6 +742,19 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __r
         float gx = inv_rho0 * (gs * dx), gy = inv_rho0 * (gs * dy), gz = inv_rho0 * (gs * dz);
         grad_sum += dot3(gx, gy, gz, gx, gy, gz);
     });
+    if (BND) {
+        const float mi = UNIFORM_MASS ? uniform_mass : pos[i].w;
+        for_each_neighbor<SWEEP_BATCH>(i, fb_count[i], fb, cap, bpos, 0u, [&](uint32_t, const float4& pb) {
+            float dx = xi.x - pb.x, dy = xi.y - pb.y, dz = xi.z - pb.z;
+            float distance = sqrt_rn(dot3(dx, dy, dz, dx, dy, dz));
+            float psi = rho0 * pb.w;  // rho0 * V_b
+            dens += psi * poly6_strict(kc, distance);
+            float gs = grad_scalar_strict<GRAD>(kc, distance);
+            float s = inv_rho0 * (psi / mi);
+            float gx = s * (gs * dx), gy = s * (gs * dy), gz = s * (gs * dz);
+            grad_sum += dot3(gx, gy, gz, gx, gy, gz);
+        });
+    }
     float C = dens / rho0 - 1.f;
     float lam = -C;
     lam /= grad_sum + kc.epsilon;
@@ -740,14 +767,17 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __r
 // Jacobi hand-over copy directly (UpdatePredictPosition, :714-721), plus the build-side
 // container clamp.  Accumulates onto new_i in neighbour-row order like the reference.
 
-template <int GRAD>
+template <int GRAD, bool BND>
 __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
                                                  float4* __restrict__ prd_out,
                                                  const uint32_t* __restrict__ nbr,
                                                  const uint32_t* __restrict__ nbr_count,
                                                  uint32_t n, uint32_t cap, KernConsts kc,
                                                  const float* __restrict__ rho0_ptr,
-                                                 int container, float3_ cmin, float3_ cmax) {
+                                                 int container, float3_ cmin, float3_ cmax,
+                                                 const float4* __restrict__ bprd,
+                                                 const uint32_t* __restrict__ fb,
+                                                 const uint32_t* __restrict__ fb_count) {
     uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float inv_rho0 = 1.f / *rho0_ptr;
@@ -764,6 +794,17 @@ __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
         ny += s * (gs * dy);
         nz += s * (gs * dz);
     });
+    if (BND) {  // pbf_correction_boundary (cuda_simulation.cu:990-1046): no s_corr term
+        for_each_neighbor<SWEEP_BATCH>(i, fb_count[i], fb, cap, bprd, 0u, [&](uint32_t, const float4& pb) {
+            float dx = xi.x - pb.x, dy = xi.y - pb.y, dz = xi.z - pb.z;
+            float distance = sqrt_rn(dot3(dx, dy, dz, dx, dy, dz));
+            float gs = grad_scalar_strict<GRAD>(kc, distance);
+            float s = inv_rho0 * (xi.w + pb.w);
+            nx += s * (gs * dx);
+            ny += s * (gs * dy);
+            nz += s * (gs * dz);
+        });
+    }
     if (container) {
         nx = nx < cmin.x ? cmin.x : nx;
         nx = nx > cmax.x ? cmax.x : nx;
@@ -773,6 +814,147 @@ __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
         nz = nz > cmax.z ? cmax.z : nz;
     }
     prd_out[i] = make_float4(nx, ny, nz, xi.w);
+}
+
+// ------------------------------------------------------------------------------------
+// Boundary particles (PARITY UNPINNED): the Akinci coupling of the
+// reference's CUDA kernels (cuda_simulation.cu K5 :331-374, K7 :1128-1212, K9 :1296-1384 and the
+// boundary halves of K6/K8/K10) in the CPU path's arithmetic and frozen-list semantics, as
+// checked against the CPU oracle.  The set is static: sorted once on the ctx grid as
+//   bpos [nb] float4 (x, y, z, V_b)     bprd [nb] float4 (x, y, z, lambda_b)
+// with three neighbour tables: bb (boundary-boundary, static), fb (fluid -> boundary) and bf
+// (boundary -> fluid), the last two rebuilt with the fluid table every sub-step.
+
+__global__ __launch_bounds__(BLOCK) void k_boundary_pack(const float* __restrict__ pos3,
+                                                         const float* __restrict__ mass,
+                                                         float uniform_mass, uint32_t nb,
+                                                         float4* __restrict__ raw,
+                                                         uint32_t* __restrict__ id) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nb) return;
+    raw[i] = make_float4(pos3[3 * (size_t)i], pos3[3 * (size_t)i + 1], pos3[3 * (size_t)i + 2],
+                         mass ? mass[i] : uniform_mass);
+    id[i] = i;
+}
+
+// rank by index inside the cell (= stable sort) + gather, as k_reorder
+__global__ __launch_bounds__(BLOCK) void k_boundary_reorder(
+    const uint32_t* __restrict__ key, const uint32_t* __restrict__ cell_start,
+    const uint32_t* __restrict__ tmp_src, const uint32_t* __restrict__ tmp_id, uint32_t nb,
+    const float4* __restrict__ raw, float4* __restrict__ bprd, float* __restrict__ bmass,
+    uint32_t* __restrict__ bid) {
+    uint32_t s = blockIdx.x * BLOCK + threadIdx.x;
+    if (s >= nb) return;
+    const uint32_t src = tmp_src[s], my = tmp_id[s];
+    const uint32_t k = key[src];
+    const uint32_t a = cell_start[k], b = cell_start[k + 1];
+    uint32_t rank = 0;
+    for (uint32_t t = a; t < b; ++t) rank += (tmp_id[t] < my) ? 1u : 0u;
+    const uint32_t dst = a + rank;
+    const float4 v = raw[src];
+    bprd[dst] = make_float4(v.x, v.y, v.z, 0.f);
+    bmass[dst] = v.w;
+    bid[dst] = my;
+}
+
+// K5 compute_boundary_volume_d: V_b = m_b / (m_b W(0) + sum_b' m_b' W(|p_b - p_b'|))
+__global__ __launch_bounds__(BLOCK) void k_boundary_volume(const float4* __restrict__ bprd,
+                                                           const float* __restrict__ bmass,
+                                                           const uint32_t* __restrict__ bb,
+                                                           const uint32_t* __restrict__ bb_count,
+                                                           uint32_t nb, KernConsts kc,
+                                                           float4* __restrict__ bpos) {
+    uint32_t b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= nb) return;
+    const float4 pb = bprd[b];
+    const float mb = bmass[b];
+    float rho = mb * kc.w_zero;
+    for_each_neighbor<SWEEP_BATCH>(b, bb_count[b], bb, nb, bprd, [&](uint32_t o, const float4& po) {
+        float ex = po.x - pb.x, ey = po.y - pb.y, ez = po.z - pb.z;
+        float distance = sqrt_rn(dot3(ex, ey, ez, ex, ey, ez));
+        rho += bmass[o] * poly6_strict(kc, distance);
+    });
+    bpos[b] = make_float4(pb.x, pb.y, pb.z, mb / rho);
+}
+
+// the boundary-boundary part of K7 + K9: it comes first in both running sums and never changes
+// (static positions), so the prefix of each sum is kept and the per-iteration kernel continues
+// from it -- same fp32 summation order as summing everything each time
+template <int GRAD>
+__global__ __launch_bounds__(BLOCK) void k_boundary_static(const float4* __restrict__ bpos,
+                                                           const float* __restrict__ bmass,
+                                                           const uint32_t* __restrict__ bb,
+                                                           const uint32_t* __restrict__ bb_count,
+                                                           uint32_t nb, KernConsts kc,
+                                                           const float* __restrict__ rho0_ptr,
+                                                           float* __restrict__ rho_s,
+                                                           float* __restrict__ grad_s) {
+    uint32_t b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= nb) return;
+    const float rho0 = *rho0_ptr;
+    const float inv_rho0 = 1.f / rho0;
+    const float4 pb = bpos[b];
+    float rho = (rho0 * pb.w) * kc.w_zero;
+    float grad_sum = 0.f;
+    for_each_neighbor<SWEEP_BATCH>(b, bb_count[b], bb, nb, bpos, [&](uint32_t o, const float4& po) {
+        float dx = pb.x - po.x, dy = pb.y - po.y, dz = pb.z - po.z;
+        float distance = sqrt_rn(dot3(dx, dy, dz, dx, dy, dz));
+        float psi = rho0 * po.w;
+        rho += psi * poly6_strict(kc, distance);
+        float gs = grad_scalar_strict<GRAD>(kc, distance);
+        float s = inv_rho0 * (psi / bmass[o]);
+        float gx = s * (gs * dx), gy = s * (gs * dy), gz = s * (gs * dz);
+        grad_sum += dot3(gx, gy, gz, gx, gy, gz);
+    });
+    rho_s[b] = rho;
+    grad_s[b] = grad_sum;
+}
+
+// K7 compute_boundary_density_d + K9 compute_boundary_lambdas_d on the current predicted
+// fluid positions; lambda_b goes into bprd[b].w
+template <bool UNIFORM_MASS, int GRAD>
+__global__ __launch_bounds__(BLOCK) void k_boundary_lambda(
+    const float4* __restrict__ bpos, float4* bprd, const float4* __restrict__ prd,
+    const float4* __restrict__ pos, const uint32_t* __restrict__ bf,
+    const uint32_t* __restrict__ bf_count, uint32_t nb, KernConsts kc,
+    const float* __restrict__ rho0_ptr, float uniform_mass, const float* __restrict__ rho_s,
+    const float* __restrict__ grad_s, float* __restrict__ bdens) {
+    uint32_t b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= nb) return;
+    const float rho0 = *rho0_ptr;
+    const float inv_rho0 = 1.f / rho0;
+    const float4 pb = bpos[b];
+    float rho = rho_s[b];
+    float grad_sum = grad_s[b];
+    for_each_neighbor<SWEEP_BATCH>(b, bf_count[b], bf, nb, prd, 0u, [&](uint32_t j, const float4& xj) {
+        float mj = UNIFORM_MASS ? uniform_mass : pos[j].w;
+        float dx = pb.x - xj.x, dy = pb.y - xj.y, dz = pb.z - xj.z;
+        float distance = sqrt_rn(dot3(dx, dy, dz, dx, dy, dz));
+        rho += mj * poly6_strict(kc, distance);
+        float gs = grad_scalar_strict<GRAD>(kc, distance);
+        float gx = inv_rho0 * (gs * dx), gy = inv_rho0 * (gs * dy), gz = inv_rho0 * (gs * dz);
+        grad_sum += dot3(gx, gy, gz, gx, gy, gz);
+    });
+    bdens[b] = rho;
+    float C = rho / rho0 - 1.f;
+    float lam = -C;
+    lam /= grad_sum + kc.epsilon;
+    reinterpret_cast<float*>(bprd)[4 * (size_t)b + 3] = lam;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_boundary_unpack(const float4* __restrict__ bpos,
+                                                           const float* __restrict__ bdens,
+                                                           const float4* __restrict__ bprd,
+                                                           const uint32_t* __restrict__ bid,
+                                                           uint32_t nb, float* __restrict__ o_vol,
+                                                           float* __restrict__ o_dens,
+                                                           float* __restrict__ o_lam) {
+    uint32_t b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= nb) return;
+    const uint32_t o = bid[b];
+    o_vol[o] = bpos[b].w;
+    o_dens[o] = bdens[b];
+    o_lam[o] = bprd[b].w;
 }
 
 // a18: ParticleSet::Update (Particle.cpp:207-215): v = (new - p) / dt; p = new
@@ -1108,6 +1290,7 @@ __global__ __launch_bounds__(BLOCK) void k_cells_by_id(const float4* __restrict_
 __global__ __launch_bounds__(BLOCK) void k_neighbors_by_id(const uint32_t* __restrict__ nbr,
                                                            const uint32_t* __restrict__ nbr_count,
                                                            const uint32_t* __restrict__ id,
+                                                           const uint32_t* __restrict__ target_id,
                                                            uint32_t n, uint32_t cap, uint32_t stride,
                                                            uint32_t* __restrict__ counts,
                                                            uint32_t* __restrict__ out) {
@@ -1117,7 +1300,7 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors_by_id(const uint32_t* __res
     uint32_t cnt = nbr_count[i];
     counts[o] = cnt;
     for (uint32_t k = 0; k < cnt && k < stride; ++k)
-        out[(size_t)o * stride + k] = id[nbr[(size_t)k * cap + i]];
+        out[(size_t)o * stride + k] = target_id[nbr[(size_t)k * cap + i]];
 }
 
 // exhaustive check of sqrt_rn against the compiler's correctly rounded sqrtf
@@ -1255,6 +1438,14 @@ struct pbf_ctx {
     const float* mig_out[2] = {nullptr, nullptr};   // this step's migrant records (caller's buffers)
     uint32_t mig_out_count[2] = {0, 0}, split_max = 0;
     SlabCounters* slab_cnt = nullptr;
+    // boundary particles (static set; see k_boundary_*)
+    uint32_t nb = 0, Kb = 0;
+    float4 *bpos = nullptr, *bprd = nullptr;
+    float *bmass = nullptr, *bdens = nullptr, *b_rho_s = nullptr, *b_grad_s = nullptr;
+    uint32_t *bid = nullptr, *b_cell_start = nullptr;
+    uint32_t *bb = nullptr, *bb_count = nullptr, *bf = nullptr, *bf_count = nullptr;
+    uint32_t *fb = nullptr, *fb_count = nullptr;
+    bool b_static_valid = false;
     bool owns_stream = true;
     bool uniform = false;      // every particle has uniform_mass (no per-neighbour mass gather)
     float uniform_mass = 0.f;
@@ -1447,10 +1638,22 @@ int sort_and_neighbors(pbf_ctx* c) {
     if (n) {
         PhaseScope ps(c, PH_NEIGHBORS);
         HIP_CK(c, hipMemsetAsync(c->flags, 0, sizeof(DevFlags), c->stream));
-        k_neighbors<<<nblocks(n), BLOCK, 0, c->stream>>>(
-            c->prd[c->prd_cur], c->cell_start, n, c->cap, c->K, G,
+        k_neighbors<true><<<nblocks(n), BLOCK, 0, c->stream>>>(
+            c->prd[c->prd_cur], c->prd[c->prd_cur], c->cell_start, n, c->cap, c->K, G,
             c->P.effective_radius * c->P.effective_radius, c->nbr, c->nbr_count, c->flags);
+        if (c->nb) {
+            // fluid -> boundary and boundary -> fluid rows, frozen for the sub-step like the fluid's
+            const float hh = c->P.effective_radius * c->P.effective_radius;
+            k_neighbors<false><<<nblocks(n), BLOCK, 0, c->stream>>>(
+                c->prd[c->prd_cur], c->bpos, c->b_cell_start, n, c->cap, c->Kb, G, hh, c->fb,
+                c->fb_count, c->flags);
+            k_neighbors<false><<<nblocks(c->nb), BLOCK, 0, c->stream>>>(
+                c->bpos, c->prd[c->prd_cur], c->cell_start, c->nb, c->nb, c->Kb, G, hh, c->bf,
+                c->bf_count, c->flags);
+        }
         LAUNCH_CK(c);
+    } else if (c->nb) {
+        HIP_CK(c, hipMemsetAsync(c->bf_count, 0, (size_t)c->nb * 4, c->stream));
     }
     c->keyed = false;
     c->grid_valid = true;
@@ -1465,6 +1668,19 @@ int download3(pbf_ctx* c, const float4* src, float* host) {
     HIP_CK(c, hipMemcpyAsync(host, st, (size_t)c->n * 12, hipMemcpyDeviceToHost, c->stream));
     HIP_CK(c, hipStreamSynchronize(c->stream));
     return PBF_OK;
+}
+
+void free_boundary(pbf_ctx* c) {
+    (void)hipFree(c->bpos); (void)hipFree(c->bprd); (void)hipFree(c->bmass); (void)hipFree(c->bdens);
+    (void)hipFree(c->b_rho_s); (void)hipFree(c->b_grad_s); (void)hipFree(c->bid);
+    (void)hipFree(c->b_cell_start); (void)hipFree(c->bb); (void)hipFree(c->bb_count);
+    (void)hipFree(c->bf); (void)hipFree(c->bf_count); (void)hipFree(c->fb); (void)hipFree(c->fb_count);
+    c->bpos = c->bprd = nullptr;
+    c->bmass = c->bdens = c->b_rho_s = c->b_grad_s = nullptr;
+    c->bid = c->b_cell_start = c->bb = c->bb_count = c->bf = c->bf_count = c->fb = c->fb_count = nullptr;
+    c->nb = 0;
+    c->Kb = 0;
+    c->b_static_valid = false;
 }
 
 int check_flags(pbf_ctx* c) {
@@ -1622,6 +1838,7 @@ int pbf_destroy(pbf_ctx* c) {
     (void)hipFree(c->blist[0]);
     (void)hipFree(c->blist[1]);
     (void)hipFree(c->slab_cnt);
+    free_boundary(c);
     if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PBF_OK;
@@ -1647,6 +1864,7 @@ static int upload_common(pbf_ctx* c, const float* d_pos, const float* d_vel, con
     c->first_frame = true;
     c->keyed = false;
     c->grid_valid = false;
+    c->b_static_valid = false;
     return PBF_OK;
 }
 
@@ -1713,6 +1931,154 @@ int pbf_set_gravity(pbf_ctx* c, float gx, float gy, float gz) {
     return PBF_OK;
 }
 
+int pbf_set_boundary(pbf_ctx* c, const float* pos, const float* mass, float uniform_mass,
+                     uint32_t nb, uint32_t max_boundary_neighbors) {
+    ENTER(c);
+    if (c->slab) return fail(c, PBF_ERR_INVALID, "boundary particles are not supported in slab mode yet");
+    if (nb && !pos) return fail(c, PBF_ERR_INVALID, "pos is null");
+    if (nb && !mass && !(uniform_mass > 0.f)) return fail(c, PBF_ERR_INVALID, "uniform_mass must be > 0");
+    if (max_boundary_neighbors > 1024) return fail(c, PBF_ERR_INVALID, "max_boundary_neighbors out of range");
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    free_boundary(c);
+    c->grid_valid = false;  // the fluid<->boundary rows of the last search are gone
+    if (!nb) return PBF_OK;
+    const uint32_t Kb = max_boundary_neighbors ? max_boundary_neighbors : c->K;
+    const size_t cap = c->cap;
+    float *d_pos3 = nullptr, *d_mass = nullptr;
+    float4* raw = nullptr;
+    uint32_t *key = nullptr, *tsrc = nullptr, *tid = nullptr, *ident = nullptr;
+    auto drop_tmp = [&]() {
+        (void)hipFree(d_pos3); (void)hipFree(d_mass); (void)hipFree(raw); (void)hipFree(key);
+        (void)hipFree(tsrc); (void)hipFree(tid); (void)hipFree(ident);
+    };
+#define B_CK(call)                                                                   \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            (void)hipStreamSynchronize(c->stream);                                   \
+            drop_tmp();                                                              \
+            free_boundary(c);                                                        \
+            return fail(c, PBF_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        }                                                                            \
+    } while (0)
+    B_CK(dalloc(&c->bpos, (size_t)nb));
+    B_CK(dalloc(&c->bprd, (size_t)nb));
+    B_CK(dalloc(&c->bmass, (size_t)nb));
+    B_CK(dalloc(&c->bdens, (size_t)nb));
+    B_CK(dalloc(&c->b_rho_s, (size_t)nb));
+    B_CK(dalloc(&c->b_grad_s, (size_t)nb));
+    B_CK(dalloc(&c->bid, (size_t)nb));
+    B_CK(dalloc(&c->b_cell_start, (size_t)c->ncell + 1));
+    B_CK(dalloc(&c->bb, (size_t)nb * Kb));
+    B_CK(dalloc(&c->bb_count, (size_t)nb));
+    B_CK(dalloc(&c->bf, (size_t)nb * Kb));
+    B_CK(dalloc(&c->bf_count, (size_t)nb));
+    B_CK(dalloc(&c->fb, cap * Kb));
+    B_CK(dalloc(&c->fb_count, cap));
+    B_CK(dalloc(&d_pos3, (size_t)nb * 3));
+    if (mass) B_CK(dalloc(&d_mass, (size_t)nb));
+    B_CK(dalloc(&raw, (size_t)nb));
+    B_CK(dalloc(&key, (size_t)nb));
+    B_CK(dalloc(&tsrc, (size_t)nb));
+    B_CK(dalloc(&tid, (size_t)nb));
+    B_CK(dalloc(&ident, (size_t)nb));
+    B_CK(hipMemcpyAsync(d_pos3, pos, (size_t)nb * 12, hipMemcpyHostToDevice, c->stream));
+    if (mass) B_CK(hipMemcpyAsync(d_mass, mass, (size_t)nb * 4, hipMemcpyHostToDevice, c->stream));
+    B_CK(hipMemsetAsync(c->bdens, 0, (size_t)nb * 4, c->stream));
+    B_CK(hipMemsetAsync(c->bf_count, 0, (size_t)nb * 4, c->stream));
+    B_CK(hipMemsetAsync(c->fb_count, 0, cap * 4, c->stream));
+    // the cell histogram is all zero between sub-steps unless a predict is pending
+    if (c->keyed) {
+        B_CK(hipMemsetAsync(c->cell_count, 0, (size_t)c->ncell * 4, c->stream));
+        c->keyed = false;
+    }
+    const GridConsts G = make_grid(c->P);
+    const uint32_t nbb = nblocks(nb);
+    k_boundary_pack<<<nbb, BLOCK, 0, c->stream>>>(d_pos3, d_mass, uniform_mass, nb, raw, ident);
+    k_rekey<<<nbb, BLOCK, 0, c->stream>>>(raw, key, c->cell_count, nb, G);
+    k_scan_tile_sums<<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums);
+    k_scan_sums<<<1, BLOCK, 0, c->stream>>>(c->tile_sums, c->ntiles);
+    k_scan_apply<<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
+                                                     c->b_cell_start, c->cursor);
+    k_scatter<<<nbb, BLOCK, 0, c->stream>>>(key, ident, c->cursor, nb, tsrc, tid);
+    k_boundary_reorder<<<nbb, BLOCK, 0, c->stream>>>(key, c->b_cell_start, tsrc, tid, nb, raw, c->bprd,
+                                                     c->bmass, c->bid);
+    B_CK(hipGetLastError());
+    B_CK(hipMemsetAsync(c->flags, 0, sizeof(DevFlags), c->stream));
+    k_neighbors<true><<<nbb, BLOCK, 0, c->stream>>>(c->bprd, c->bprd, c->b_cell_start, nb, nb, Kb, G,
+                                                    c->P.effective_radius * c->P.effective_radius,
+                                                    c->bb, c->bb_count, c->flags);
+    k_boundary_volume<<<nbb, BLOCK, 0, c->stream>>>(c->bprd, c->bmass, c->bb, c->bb_count, nb,
+                                                    make_kern(c->P, 0.f), c->bpos);
+    B_CK(hipGetLastError());
+    B_CK(hipStreamSynchronize(c->stream));
+#undef B_CK
+    drop_tmp();
+    c->nb = nb;
+    c->Kb = Kb;
+    int rc = check_flags(c);
+    if (rc) {
+        std::string why = c->err;
+        free_boundary(c);
+        return fail(c, rc, "boundary-boundary table: " + why);
+    }
+    return PBF_OK;
+}
+
+uint32_t pbf_num_boundary_particles(const pbf_ctx* c) { return c ? c->nb : 0; }
+
+int pbf_get_boundary(pbf_ctx* c, float* volume, float* density, float* lambda) {
+    ENTER(c);
+    const uint32_t nb = c->nb;
+    if (!nb) return PBF_OK;
+    float* d = nullptr;
+    HIP_CK(c, dalloc(&d, (size_t)nb * 3));
+    k_boundary_unpack<<<nblocks(nb), BLOCK, 0, c->stream>>>(c->bpos, c->bdens, c->bprd, c->bid, nb, d,
+                                                            d + nb, d + 2 * (size_t)nb);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && volume) e = hipMemcpyAsync(volume, d, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && density) e = hipMemcpyAsync(density, d + nb, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && lambda) e = hipMemcpyAsync(lambda, d + 2 * (size_t)nb, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, PBF_ERR_HIP, std::string("get_boundary: ") + hipGetErrorString(e));
+    return PBF_OK;
+}
+
+int pbf_get_boundary_neighbors(pbf_ctx* c, uint32_t* fluid_counts, uint32_t* fluid_to_boundary,
+                               uint32_t stride_f, uint32_t* boundary_counts,
+                               uint32_t* boundary_to_fluid, uint32_t stride_b) {
+    ENTER(c);
+    if (!c->nb) return fail(c, PBF_ERR_INVALID, "no boundary particles");
+    if (!c->grid_valid) return fail(c, PBF_ERR_INVALID, "pbf_build_grid must run first");
+    if (!fluid_counts || !fluid_to_boundary || !boundary_counts || !boundary_to_fluid || !stride_f || !stride_b)
+        return fail(c, PBF_ERR_INVALID, "null output");
+    const uint32_t n = c->n, nb = c->nb;
+    uint32_t *d_fc = nullptr, *d_fl = nullptr, *d_bc = nullptr, *d_bl = nullptr;
+    hipError_t e = dalloc(&d_fc, (size_t)n);
+    if (e == hipSuccess) e = dalloc(&d_fl, (size_t)n * stride_f);
+    if (e == hipSuccess) e = dalloc(&d_bc, (size_t)nb);
+    if (e == hipSuccess) e = dalloc(&d_bl, (size_t)nb * stride_b);
+    if (e == hipSuccess) e = hipMemsetAsync(d_fl, 0, (size_t)(n ? n : 1) * stride_f * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_bl, 0, (size_t)nb * stride_b * 4, c->stream);
+    if (e == hipSuccess) {
+        if (n)
+            k_neighbors_by_id<<<nblocks(n), BLOCK, 0, c->stream>>>(c->fb, c->fb_count, c->id[c->cur], c->bid, n,
+                                                                   c->cap, stride_f, d_fc, d_fl);
+        k_neighbors_by_id<<<nblocks(nb), BLOCK, 0, c->stream>>>(c->bf, c->bf_count, c->bid, c->id[c->cur], nb,
+                                                                nb, stride_b, d_bc, d_bl);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && n) e = hipMemcpyAsync(fluid_counts, d_fc, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(fluid_to_boundary, d_fl, (size_t)n * stride_f * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(boundary_counts, d_bc, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(boundary_to_fluid, d_bl, (size_t)nb * stride_b * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_fc); (void)hipFree(d_fl); (void)hipFree(d_bc); (void)hipFree(d_bl);
+    if (e != hipSuccess) return fail(c, PBF_ERR_HIP, std::string("get_boundary_neighbors: ") + hipGetErrorString(e));
+    return PBF_OK;
+}
+
 int pbf_predict(pbf_ctx* c, float dt) {
     ENTER(c);
     if (c->keyed) HIP_CK(c, hipMemsetAsync(c->cell_count, 0, (size_t)c->ncell * 4, c->stream));
@@ -1753,6 +2119,7 @@ int pbf_compute_rest_density(pbf_ctx* c) {
         k_rest_density_mean<<<1, 64, 0, c->stream>>>(by_id, c->n, c->rho0);
         LAUNCH_CK(c);
     }
+    c->b_static_valid = false;  // rho0 changed
     c->first_frame = false;
     return PBF_OK;
 }
@@ -1764,27 +2131,56 @@ static int solve_half(pbf_ctx* c, int half, float dt) {
     float4* x = c->prd[c->prd_cur];
     if (half == 0) {
         PhaseScope ps(c, PH_LAMBDA);
-#define LAUNCH_LAMBDA(U, G)                                                                   \
-    k_lambda<U, G><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count, c->n, \
-                                                c->cap, kc, c->rho0, c->uniform_mass, c->dens, c->C)
-        if (c->uniform && !spiky) LAUNCH_LAMBDA(true, PBF_GRAD_POLY6);
-        else if (c->uniform) LAUNCH_LAMBDA(true, PBF_GRAD_SPIKY);
-        else if (!spiky) LAUNCH_LAMBDA(false, PBF_GRAD_POLY6);
-        else LAUNCH_LAMBDA(false, PBF_GRAD_SPIKY);
+#define LAUNCH_LAMBDA(U, G, B)                                                                \
+    k_lambda<U, G, B><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count, c->n, \
+                                                   c->cap, kc, c->rho0, c->uniform_mass, c->dens, \
+                                                   c->C, c->bpos, c->fb, c->fb_count)
+#define LAUNCH_LAMBDA_UG(U, G)            \
+    do {                                  \
+        if (c->nb) LAUNCH_LAMBDA(U, G, true); \
+        else LAUNCH_LAMBDA(U, G, false);  \
+    } while (0)
+        if (c->uniform && !spiky) LAUNCH_LAMBDA_UG(true, PBF_GRAD_POLY6);
+        else if (c->uniform) LAUNCH_LAMBDA_UG(true, PBF_GRAD_SPIKY);
+        else if (!spiky) LAUNCH_LAMBDA_UG(false, PBF_GRAD_POLY6);
+        else LAUNCH_LAMBDA_UG(false, PBF_GRAD_SPIKY);
+#undef LAUNCH_LAMBDA_UG
 #undef LAUNCH_LAMBDA
+        if (c->nb) {
+            const uint32_t nbb = nblocks(c->nb);
+            if (!c->b_static_valid) {
+                if (spiky)
+                    k_boundary_static<PBF_GRAD_SPIKY><<<nbb, BLOCK, 0, c->stream>>>(
+                        c->bpos, c->bmass, c->bb, c->bb_count, c->nb, kc, c->rho0, c->b_rho_s, c->b_grad_s);
+                else
+                    k_boundary_static<PBF_GRAD_POLY6><<<nbb, BLOCK, 0, c->stream>>>(
+                        c->bpos, c->bmass, c->bb, c->bb_count, c->nb, kc, c->rho0, c->b_rho_s, c->b_grad_s);
+                c->b_static_valid = true;
+            }
+#define LAUNCH_BLAMBDA(U, G)                                                                     \
+    k_boundary_lambda<U, G><<<nbb, BLOCK, 0, c->stream>>>(c->bpos, c->bprd, x, c->pos[c->cur], c->bf, \
+                                                          c->bf_count, c->nb, kc, c->rho0,       \
+                                                          c->uniform_mass, c->b_rho_s, c->b_grad_s, c->bdens)
+            if (c->uniform && !spiky) LAUNCH_BLAMBDA(true, PBF_GRAD_POLY6);
+            else if (c->uniform) LAUNCH_BLAMBDA(true, PBF_GRAD_SPIKY);
+            else if (!spiky) LAUNCH_BLAMBDA(false, PBF_GRAD_POLY6);
+            else LAUNCH_BLAMBDA(false, PBF_GRAD_SPIKY);
+#undef LAUNCH_BLAMBDA
+        }
     } else {
         PhaseScope ps(c, PH_DELTA);
         float3_ cmin = {c->P.container_min[0], c->P.container_min[1], c->P.container_min[2]};
         float3_ cmax = {c->P.container_max[0], c->P.container_max[1], c->P.container_max[2]};
         float4* y = c->prd[(c->prd_cur + 1) % 3];
-        if (!spiky)
-            k_delta<PBF_GRAD_POLY6><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n,
-                                                                 c->cap, kc, c->rho0,
-                                                                 c->P.container_enabled, cmin, cmax);
-        else
-            k_delta<PBF_GRAD_SPIKY><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n,
-                                                                 c->cap, kc, c->rho0,
-                                                                 c->P.container_enabled, cmin, cmax);
+#define LAUNCH_DELTA(G, B)                                                                        \
+    k_delta<G, B><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n, c->cap, kc, c->rho0, \
+                                               c->P.container_enabled, cmin, cmax, c->bprd, c->fb, \
+                                               c->fb_count)
+        if (!spiky && !c->nb) LAUNCH_DELTA(PBF_GRAD_POLY6, false);
+        else if (!spiky) LAUNCH_DELTA(PBF_GRAD_POLY6, true);
+        else if (!c->nb) LAUNCH_DELTA(PBF_GRAD_SPIKY, false);
+        else LAUNCH_DELTA(PBF_GRAD_SPIKY, true);
+#undef LAUNCH_DELTA
         c->prd_cur = (c->prd_cur + 1) % 3;
     }
     LAUNCH_CK(c);
@@ -1908,6 +2304,7 @@ int pbf_slab_set_bounds(pbf_ctx* c, int32_t x_lo, int32_t x_hi, int32_t ghost_la
     if (ghost_layers < 1 || ghost_layers > 8) return fail(c, PBF_ERR_INVALID, "ghost_layers must be in [1, 8]");
     if (c->P.rest_density_mode != PBF_RHO0_FIXED)
         return fail(c, PBF_ERR_INVALID, "slab mode needs PBF_RHO0_FIXED (the first-frame mean is a serial global sum)");
+    if (c->nb) return fail(c, PBF_ERR_INVALID, "boundary particles are not supported in slab mode yet");
     c->slab = true;
     c->x_lo = x_lo;
     c->x_hi = x_hi;
@@ -2192,8 +2589,9 @@ int pbf_get_neighbors(pbf_ctx* c, uint32_t* counts, uint32_t* neighbors, uint32_
         return fail(c, PBF_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
     (void)hipMemsetAsync(d_out, 0, (size_t)n * stride * 4, c->stream);
-    k_neighbors_by_id<<<nblocks(n), BLOCK, 0, c->stream>>>(c->nbr, c->nbr_count, c->id[c->cur], n,
-                                                           c->cap, stride, d_counts, d_out);
+    k_neighbors_by_id<<<nblocks(n), BLOCK, 0, c->stream>>>(c->nbr, c->nbr_count, c->id[c->cur],
+                                                           c->id[c->cur], n, c->cap, stride,
+                                                           d_counts, d_out);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(counts, d_counts, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(neighbors, d_out, (size_t)n * stride * 4, hipMemcpyDeviceToHost, c->stream);

@@ -167,3 +167,72 @@ def boundary_particles_reference():
     out.append(bf.reshape(-1, 3))
     assert thickness == 1
     return np.concatenate(out, axis=0).astype(F), float(mass)
+
+
+def box_boundary_particles(lo, hi, d, top=False):
+    """One-layer particle walls around the box [lo, hi]: floor, four side
+    walls (and optionally a lid) on planes half a spacing outside the box, lattice spacing d.
+    Edge/corner columns belong to one wall only (no duplicates)."""
+    lo = np.asarray(lo, F)
+    hi = np.asarray(hi, F)
+    d = F(d)
+    half = F(0.5) * d
+
+    def axis(a, b):
+        n = int(np.ceil(float((b - a) / d))) + 2          # one extra column on each side
+        return (a - half) + d * np.arange(n, dtype=F)
+
+    xs, ys, zs = axis(lo[0], hi[0]), axis(lo[1], hi[1]), axis(lo[2], hi[2])
+    out = []
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    out.append(np.stack([X, np.full_like(X, lo[1] - half), Z], -1).reshape(-1, 3))      # floor
+    if top:
+        out.append(np.stack([X, np.full_like(X, ys[-1]), Z], -1).reshape(-1, 3))
+    yy = ys[1:-1] if top else ys[1:]
+    Y, Z = np.meshgrid(yy, zs, indexing="ij")
+    out.append(np.stack([np.full_like(Y, xs[0]), Y, Z], -1).reshape(-1, 3))             # x-
+    out.append(np.stack([np.full_like(Y, xs[-1]), Y, Z], -1).reshape(-1, 3))            # x+
+    X, Y = np.meshgrid(xs[1:-1], yy, indexing="ij")
+    out.append(np.stack([X, Y, np.full_like(X, zs[0])], -1).reshape(-1, 3))             # z-
+    out.append(np.stack([X, Y, np.full_like(X, zs[-1])], -1).reshape(-1, 3))            # z+
+    return np.concatenate(out, 0).astype(F)
+
+
+def boundary_tank(nx, ny, nz, iterations=4, tank_x_factor=2.0, wall_height_factor=1.5, **kw):
+    """dam_break's fluid block held by PARTICLE walls instead of planes/clamp: returns
+    (params, pos, mass, colliders=[], boundary_pos, boundary_mass).  Parameters as the
+    reference's CUDA scene (h = 0.0415, rho0 = 1000, eps = 100, s_corr ~ dt^3)."""
+    p, pos, mass, _cols = dam_break(nx, ny, nz, iterations=iterations, tank_x_factor=tank_x_factor, **kw)
+    h, r, _v, _m, _rho = sim_params_constants()
+    d = F(F(2.0) * r)
+    lo = np.zeros(3, F)
+    hi = np.array([F(tank_x_factor) * d * F(nx), F(wall_height_factor) * d * F(ny), d * F(nz)], F)
+    bpos = box_boundary_particles(lo, hi, d)
+    p.container_enabled = 0
+    # the walls sit half a spacing outside the box: two spare cells below
+    c0 = np.floor((lo - d) / h).astype(int)
+    p.grid_origin_cell[:] = [int(c0[0]) - 1, int(c0[1]) - 1, int(c0[2]) - 1]
+    return p, pos, float(mass), [], bpos, float(mass)
+
+
+def c2_reference_cuda_scene(iterations=4):
+    """The reference's README CUDA scene (C2): GenerateFluidCube's 64 000 particles above
+    InitializeBoundaryParticles' 32 000-particle open box (Simulation.cpp:356-576), SimParams of
+    Simulation.cpp:312-354; no plane colliders."""
+    h, r, _v, mass, rho0 = sim_params_constants()
+    pos, m = fluid_cube_reference()
+    bpos, bm = boundary_particles_reference()
+    p = default_params()
+    p.capacity = pos.shape[0]
+    p.max_neighbors = 96
+    p.effective_radius = float(h)
+    p.grid_spacing = float(h)
+    p.grid_dim[:] = [64, 64, 64]                       # Simulation.cpp:46
+    c0 = np.floor(bpos.min(axis=0) / h).astype(int)
+    p.grid_origin_cell[:] = [int(c0[0]) - 1, int(c0[1]) - 1, int(c0[2]) - 1]
+    p.epsilon = 100.0
+    p.scorr_dt_power = 3
+    p.rest_density_mode = PBF_RHO0_FIXED
+    p.rest_density = float(rho0)
+    p.solver_iterations = iterations
+    return p, pos, float(m), [], bpos, float(bm)

@@ -220,6 +220,28 @@ int pbf_export_positions(pbf_ctx* ctx, void* d_xyz);
 int pbf_snapshot_save(pbf_ctx* ctx, const char* path);
 int pbf_snapshot_load(pbf_ctx* ctx, const char* path);
 
+/* ---- boundary-particle walls --------------------------------------
+ * Replaces Simulation::InitializeBoundaryCudaData (Simulation.cpp:492-526: hash -> sort ->
+ * reorder -> compute_boundary_volume, cuda_simulation.cuh:49-53) and the boundary arguments of
+ * solve_sph_fluid (cuda_simulation.cuh:69-79).  The reference couples boundary particles only
+ * in its CUDA kernels (K5, K7, K9 and the boundary halves of K6/K8/K10); here that coupling is
+ * evaluated in the CPU path's arithmetic and frozen-list semantics (PARITY UNPINNED: checked
+ * against this repo's oracle only).  pos: nb x 3 floats, mass: nb floats or NULL =
+ * uniform_mass.  The set is static and survives pbf_upload; nb = 0 removes it.
+ * max_boundary_neighbors = rows of the three boundary tables (0 = max_neighbors).  Allocates;
+ * synchronises.  Not available in slab mode. */
+int pbf_set_boundary(pbf_ctx* ctx, const float* pos, const float* mass, float uniform_mass,
+                     uint32_t nb, uint32_t max_boundary_neighbors);
+uint32_t pbf_num_boundary_particles(const pbf_ctx* ctx);
+/* m_volume, m_density, m_lambda of the boundary ParticleSet (Particle.h:65-68) in boundary
+ * index order; NULLs allowed */
+int pbf_get_boundary(pbf_ctx* ctx, float* volume, float* density, float* lambda);
+/* the fluid->boundary and boundary->fluid rows of the last pbf_build_grid, by original index
+ * (as pbf_get_neighbors) */
+int pbf_get_boundary_neighbors(pbf_ctx* ctx, uint32_t* fluid_counts, uint32_t* fluid_to_boundary,
+                               uint32_t stride_f, uint32_t* boundary_counts,
+                               uint32_t* boundary_to_fluid, uint32_t stride_b);
+
 /* ---- slab decomposition over the GPUs of one node.  No counterpart in the
  * reference, which is single-GPU (cuda_simulation.cu has no multi-device code).  A ctx owns
  * the cells whose x index is in [x_lo, x_hi); neighbours exchange particle records of

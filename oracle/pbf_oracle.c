@@ -47,6 +47,15 @@ struct orc_ctx {
     uint64_t* nbr_off; /* n+1 */
     uint32_t* nbr;
     uint64_t nbr_cap;
+    /* boundary particles (static): positions, mass, volume (K5), and per
+     * iteration density / C / lambda (K7, K9) */
+    uint32_t nb;
+    float *bpos, *bmass, *bvol, *bdensity, *bC, *blambda;
+    int32_t* bcell;      /* nb*3 */
+    uint32_t* border;    /* boundary indices sorted by (cell x, y, z, index) */
+    uint64_t *bb_off, *fb_off, *bf_off; /* boundary-boundary (static), fluid->boundary, boundary->fluid */
+    uint32_t *bb, *fb, *bf;
+    uint64_t fb_cap, bf_cap;
     int first_frame;      /* m_first_frame, Simulation.cpp:17 */
     float rest_density;   /* m_rest_density */
     int32_t iterations;   /* ConstraintSolver::m_solver_iteration */
@@ -297,9 +306,12 @@ static void free_particles(orc_ctx* c) {
     c->nbr = NULL; c->nbr_cap = 0; c->table_size = 0;
 }
 
+static void free_boundary(orc_ctx* c);
+
 int orc_destroy(orc_ctx* c) {
     if (!c) return PBF_ERR_INVALID;
     free_particles(c);
+    free_boundary(c);
     free(c);
     return PBF_OK;
 }
@@ -475,6 +487,8 @@ static int ensure_nbr(orc_ctx* c, uint64_t total) {
     return PBF_OK;
 }
 
+static int boundary_search(orc_ctx* c);
+
 /* NeighborSearch::SpatialSearch, NeighborSearch.cpp:131-236 */
 int orc_spatial_search(orc_ctx* c) {
     if (!c) return PBF_ERR_INVALID;
@@ -526,6 +540,7 @@ int orc_spatial_search(orc_ctx* c) {
             if (pass == 0) c->nbr_off[i + 1] = cnt;
         }
     }
+    if (c->nb) return boundary_search(c);
     return PBF_OK;
 }
 
@@ -560,6 +575,244 @@ int orc_naive_search(orc_ctx* c) {
             }
             if (pass == 0) c->nbr_off[i + 1] = cnt;
         }
+    }
+    return PBF_OK;
+}
+
+/* ---------------------------------------------------------------- boundary particles
+ * Build-side (PARITY UNPINNED): the boundary-particle coupling of the reference's CUDA kernels
+ * (cuda_simulation.cu: K5 compute_boundary_volume_d :331-374, pbf_density_boundary :665-701,
+ * K7 compute_boundary_density_d :1128-1212, pbf_lambda_boundary :846-884, K9
+ * compute_boundary_lambdas_d :1296-1384, pbf_correction_boundary :990-1046) restated in the CPU
+ * path's conventions: fp32 vectors, SPH kernels evaluated in double, frozen per-sub-step
+ * neighbour lists (dist2 <= h*h on predicted positions), 27-cell sweep x outermost / z
+ * innermost, ascending boundary index inside a cell.  Boundary particles never move. */
+
+static int bcell_cmp(const int32_t* a, const int32_t* b) {
+    for (int k = 0; k < 3; ++k)
+        if (a[k] != b[k]) return a[k] < b[k] ? -1 : 1;
+    return 0;
+}
+
+static orc_ctx* g_sort_ctx; /* qsort has no context argument; set_boundary is single-threaded */
+static int border_cmp(const void* pa, const void* pb) {
+    uint32_t a = *(const uint32_t*)pa, b = *(const uint32_t*)pb;
+    int c = bcell_cmp(g_sort_ctx->bcell + 3 * (size_t)a, g_sort_ctx->bcell + 3 * (size_t)b);
+    if (c) return c;
+    return a < b ? -1 : (a > b ? 1 : 0);
+}
+
+/* [lo, hi) range of `border` whose cell equals `cell` */
+static void bcell_range(const orc_ctx* c, const int32_t cell[3], uint32_t* lo, uint32_t* hi) {
+    uint32_t a = 0, b = c->nb;
+    while (a < b) {
+        uint32_t m = a + (b - a) / 2;
+        if (bcell_cmp(c->bcell + 3 * (size_t)c->border[m], cell) < 0) a = m + 1; else b = m;
+    }
+    *lo = a;
+    b = c->nb;
+    while (a < b) {
+        uint32_t m = a + (b - a) / 2;
+        if (bcell_cmp(c->bcell + 3 * (size_t)c->border[m], cell) <= 0) a = m + 1; else b = m;
+    }
+    *hi = a;
+}
+
+static void free_boundary(orc_ctx* c) {
+    free(c->bpos); free(c->bmass); free(c->bvol); free(c->bdensity); free(c->bC); free(c->blambda);
+    free(c->bcell); free(c->border); free(c->bb_off); free(c->fb_off); free(c->bf_off);
+    free(c->bb); free(c->fb); free(c->bf);
+    c->bpos = c->bmass = c->bvol = c->bdensity = c->bC = c->blambda = NULL;
+    c->bcell = NULL; c->border = NULL; c->bb_off = c->fb_off = c->bf_off = NULL;
+    c->bb = c->fb = c->bf = NULL; c->fb_cap = c->bf_cap = 0; c->nb = 0;
+}
+
+/* neighbours of point p (cell g) among the boundary particles, visiting order as above;
+ * skip = boundary index to leave out (or UINT32_MAX); out may be NULL (count only) */
+static uint64_t boundary_sweep(const orc_ctx* c, const float p[3], const int32_t g[3], uint32_t skip,
+                               float square_h, uint32_t* out) {
+    uint64_t cnt = 0;
+    for (int32_t x = -1; x < 2; ++x)
+        for (int32_t y = -1; y < 2; ++y)
+            for (int32_t z = -1; z < 2; ++z) {
+                int32_t cell[3] = {g[0] + x, g[1] + y, g[2] + z};
+                uint32_t lo, hi;
+                bcell_range(c, cell, &lo, &hi);
+                for (uint32_t t = lo; t < hi; ++t) {
+                    uint32_t b = c->border[t];
+                    if (b == skip) continue;
+                    if (dist2_3(p, c->bpos + 3 * (size_t)b) <= square_h) {
+                        if (out) out[cnt] = b;
+                        ++cnt;
+                    }
+                }
+            }
+    return cnt;
+}
+
+int orc_set_boundary(orc_ctx* c, const float* pos, const float* mass, float uniform_mass, uint32_t nb) {
+    if (!c || (nb && !pos)) return PBF_ERR_INVALID;
+    free_boundary(c);
+    if (!nb) return PBF_OK;
+    c->nb = nb;
+    c->bpos = (float*)xcalloc((size_t)nb * 3, 4); c->bmass = (float*)xcalloc(nb, 4);
+    c->bvol = (float*)xcalloc(nb, 4); c->bdensity = (float*)xcalloc(nb, 4);
+    c->bC = (float*)xcalloc(nb, 4); c->blambda = (float*)xcalloc(nb, 4);
+    c->bcell = (int32_t*)xcalloc((size_t)nb * 3, 4); c->border = (uint32_t*)xcalloc(nb, 4);
+    c->bb_off = (uint64_t*)xcalloc((size_t)nb + 1, 8);
+    c->bf_off = (uint64_t*)xcalloc((size_t)nb + 1, 8);
+    memcpy(c->bpos, pos, (size_t)nb * 12);
+    for (uint32_t b = 0; b < nb; ++b) {
+        c->bmass[b] = mass ? mass[b] : uniform_mass;
+        orc_flooring(c->bpos + 3 * (size_t)b, c->P.grid_spacing, c->bcell + 3 * (size_t)b);
+        c->border[b] = b;
+    }
+    g_sort_ctx = c;
+    qsort(c->border, nb, 4, border_cmp);
+    const float h = c->P.effective_radius, square_h = h * h;
+    /* static boundary-boundary lists */
+    for (uint32_t b = 0; b < nb; ++b)
+        c->bb_off[b + 1] = c->bb_off[b] + boundary_sweep(c, c->bpos + 3 * (size_t)b, c->bcell + 3 * (size_t)b, b, square_h, NULL);
+    c->bb = (uint32_t*)xcalloc(c->bb_off[nb], 4);
+    for (uint32_t b = 0; b < nb; ++b)
+        boundary_sweep(c, c->bpos + 3 * (size_t)b, c->bcell + 3 * (size_t)b, b, square_h, c->bb + c->bb_off[b]);
+    /* K5 compute_boundary_volume_d: V_b = m_b / (m_b W(0) + sum_b' m_b' W(|p_b - p_b'|)) */
+    const kern_t k = make_kern(h, c->P.gradient_kernel);
+    for (uint32_t b = 0; b < nb; ++b) {
+        float rho = c->bmass[b] * k_poly6(&k, 0);
+        for (uint64_t a = c->bb_off[b]; a < c->bb_off[b + 1]; ++a) {
+            uint32_t o = c->bb[a];
+            float dist = dist3(c->bpos + 3 * (size_t)b, c->bpos + 3 * (size_t)o);
+            rho += c->bmass[o] * k_poly6(&k, dist);
+        }
+        c->bvol[b] = c->bmass[b] / rho;
+    }
+    return PBF_OK;
+}
+
+/* per sub-step, after the fluid lists: fluid->boundary and boundary->fluid lists */
+static int boundary_search(orc_ctx* c) {
+    const int n = (int)c->n;
+    const uint32_t nb = c->nb;
+    const float h = c->P.effective_radius, square_h = h * h;
+    free(c->fb_off);
+    c->fb_off = (uint64_t*)xcalloc((size_t)n + 1, 8);
+    for (int i = 0; i < n; ++i)
+        c->fb_off[i + 1] = c->fb_off[i] + boundary_sweep(c, c->pred + 3 * i, c->cell + 3 * i, UINT32_MAX, square_h, NULL);
+    if (c->fb_off[n] > c->fb_cap) {
+        free(c->fb);
+        c->fb = (uint32_t*)xcalloc(c->fb_off[n], 4);
+        c->fb_cap = c->fb_off[n];
+    }
+#pragma omp parallel for schedule(dynamic, 64) num_threads(c->threads)
+    for (int i = 0; i < n; ++i)
+        boundary_sweep(c, c->pred + 3 * i, c->cell + 3 * i, UINT32_MAX, square_h, c->fb + c->fb_off[i]);
+    /* boundary -> fluid through the fluid buckets (same sweep as SpatialSearch) */
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            uint64_t acc = 0;
+            for (uint32_t b = 0; b < nb; ++b) { uint64_t k = c->bf_off[b + 1]; c->bf_off[b] = acc; acc += k; }
+            c->bf_off[nb] = acc;
+            if (acc > c->bf_cap) {
+                free(c->bf);
+                c->bf = (uint32_t*)xcalloc(acc, 4);
+                c->bf_cap = acc;
+            }
+        }
+        for (uint32_t b = 0; b < nb; ++b) {
+            const float* pb = c->bpos + 3 * (size_t)b;
+            const int32_t* g = c->bcell + 3 * (size_t)b;
+            uint64_t w = (pass == 1) ? c->bf_off[b] : 0, cnt = 0;
+            for (int32_t x = -1; x < 2; ++x)
+                for (int32_t y = -1; y < 2; ++y)
+                    for (int32_t z = -1; z < 2; ++z) {
+                        bucket_t* bk = table_find(c, orc_hash_value(g[0] + x, g[1] + y, g[2] + z), 0);
+                        if (!bk) continue;
+                        for (int32_t pj = bk->head; pj >= 0; pj = c->next[pj]) {
+                            /* a hash bucket can hold aliased far cells: the exact cell test keeps
+                             * the list a function of geometry only */
+                            const int32_t* cj = c->cell + 3 * pj;
+                            if (cj[0] != g[0] + x || cj[1] != g[1] + y || cj[2] != g[2] + z) continue;
+                            if (dist2_3(pb, c->pred + 3 * pj) <= square_h) {
+                                if (pass == 1) c->bf[w++] = (uint32_t)pj;
+                                ++cnt;
+                            }
+                        }
+                    }
+            if (pass == 0) c->bf_off[b + 1] = cnt;
+        }
+    }
+    return PBF_OK;
+}
+
+/* K7 compute_boundary_density_d + K9 compute_boundary_lambdas_d on the current predicted
+ * fluid positions */
+static void boundary_density_lambda(orc_ctx* c) {
+    const kern_t k = make_kern(c->P.effective_radius, c->P.gradient_kernel);
+    const float rho0 = c->rest_density, inv_rho0 = 1.f / rho0, epsilon = c->P.epsilon;
+    const int nb = (int)c->nb;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(c->threads)
+    for (int b = 0; b < nb; ++b) {
+        const float* pb = c->bpos + 3 * (size_t)b;
+        float rho = (rho0 * c->bvol[b]) * k_poly6(&k, 0);
+        float grad_sum = 0.f;
+        for (uint64_t a = c->bb_off[b]; a < c->bb_off[b + 1]; ++a) {
+            uint32_t o = c->bb[a];
+            const float* po = c->bpos + 3 * (size_t)o;
+            float diff[3] = {pb[0] - po[0], pb[1] - po[1], pb[2] - po[2]};
+            float dist = dist3(pb, po);
+            rho += (rho0 * c->bvol[o]) * k_poly6(&k, dist);
+            float g[3];
+            k_grad(&k, diff, dist, g);
+            float s = inv_rho0 * ((rho0 * c->bvol[o]) / c->bmass[o]);
+            float gj[3] = {s * g[0], s * g[1], s * g[2]};
+            grad_sum += dot3(gj, gj);
+        }
+        for (uint64_t a = c->bf_off[b]; a < c->bf_off[b + 1]; ++a) {
+            uint32_t j = c->bf[a];
+            const float* pj = c->pred + 3 * (size_t)j;
+            float diff[3] = {pb[0] - pj[0], pb[1] - pj[1], pb[2] - pj[2]};
+            float dist = dist3(pb, pj);
+            rho += c->mass[j] * k_poly6(&k, dist);
+            float g[3];
+            k_grad(&k, diff, dist, g);
+            float gj[3] = {inv_rho0 * g[0], inv_rho0 * g[1], inv_rho0 * g[2]};
+            grad_sum += dot3(gj, gj);
+        }
+        c->bdensity[b] = rho;
+        c->bC[b] = rho / rho0 - 1.f;
+        float lam = -c->bC[b];
+        lam /= grad_sum + epsilon;
+        c->blambda[b] = lam;
+    }
+}
+
+int orc_get_boundary(orc_ctx* c, float* volume, float* density, float* lambda) {
+    if (!c) return PBF_ERR_INVALID;
+    if (volume) memcpy(volume, c->bvol, (size_t)c->nb * 4);
+    if (density) memcpy(density, c->bdensity, (size_t)c->nb * 4);
+    if (lambda) memcpy(lambda, c->blambda, (size_t)c->nb * 4);
+    return PBF_OK;
+}
+
+int orc_get_boundary_neighbors(orc_ctx* c, uint32_t* fluid_counts, uint32_t* fluid_to_boundary,
+                               uint32_t stride_f, uint32_t* boundary_counts,
+                               uint32_t* boundary_to_fluid, uint32_t stride_b) {
+    if (!c) return PBF_ERR_INVALID;
+    if (!c->nb || !c->fb_off) return PBF_ERR_INVALID;
+    for (uint32_t i = 0; i < c->n; ++i) {
+        uint64_t k = c->fb_off[i + 1] - c->fb_off[i];
+        if (fluid_counts) fluid_counts[i] = (uint32_t)k;
+        if (fluid_to_boundary)
+            for (uint64_t a = 0; a < k && a < stride_f; ++a)
+                fluid_to_boundary[(size_t)i * stride_f + a] = c->fb[c->fb_off[i] + a];
+    }
+    for (uint32_t b = 0; b < c->nb; ++b) {
+        uint64_t k = c->bf_off[b + 1] - c->bf_off[b];
+        if (boundary_counts) boundary_counts[b] = (uint32_t)k;
+        if (boundary_to_fluid)
+            for (uint64_t a = 0; a < k && a < stride_b; ++a)
+                boundary_to_fluid[(size_t)b * stride_b + a] = c->bf[c->bf_off[b] + a];
     }
     return PBF_OK;
 }
@@ -600,11 +853,19 @@ int orc_compute_density(orc_ctx* c) {
             float res = k_poly6(&k, distance);
             dens += c->mass[j] * res;
         }
+        if (c->nb) /* pbf_density_boundary, cuda_simulation.cu:665-701 */
+            for (uint64_t a = c->fb_off[i]; a < c->fb_off[i + 1]; ++a) {
+                uint32_t b = c->fb[a];
+                float distance = dist3(c->pred + 3 * i, c->bpos + 3 * (size_t)b);
+                dens += (rho0 * c->bvol[b]) * k_poly6(&k, distance);
+            }
         c->density[i] = dens;
         c->C[i] = dens / rho0 - 1.f;
     }
     return PBF_OK;
 }
+
+static void boundary_density_lambda(orc_ctx* c);
 
 /* Simulation::ComputeLambdas, Simulation.cpp:642-679 */
 int orc_compute_lambdas(orc_ctx* c) {
@@ -637,9 +898,22 @@ int orc_compute_lambdas(orc_ctx* c) {
             float dot_value = dot3(gj, gj);
             gradientC_sum += dot_value;
         }
+        if (c->nb) /* pbf_lambda_boundary, cuda_simulation.cu:846-884 */
+            for (uint64_t a = c->fb_off[i]; a < c->fb_off[i + 1]; ++a) {
+                uint32_t b = c->fb[a];
+                const float* pb = c->bpos + 3 * (size_t)b;
+                float diff[3] = {pi[0] - pb[0], pi[1] - pb[1], pi[2] - pb[2]};
+                float distance = dist3(pi, pb);
+                float g[3];
+                k_grad(&k, diff, distance, g);
+                float s = inv_rho0 * ((c->rest_density * c->bvol[b]) / c->mass[i]);
+                float gj[3] = {s * g[0], s * g[1], s * g[2]};
+                gradientC_sum += dot3(gj, gj);
+            }
         lam /= gradientC_sum + epsilon;
         c->lambda[i] = lam;
     }
+    if (c->nb) boundary_density_lambda(c);
     return PBF_OK;
 }
 
@@ -676,6 +950,17 @@ int orc_compute_correction(orc_ctx* c, float dt) {
             float s = inv_rho0 * (c->lambda[i] + c->lambda[j] + (float)scorr);
             np[0] += s * g[0]; np[1] += s * g[1]; np[2] += s * g[2];
         }
+        if (c->nb) /* pbf_correction_boundary, cuda_simulation.cu:990-1046: no s_corr term */
+            for (uint64_t a = c->fb_off[i]; a < c->fb_off[i + 1]; ++a) {
+                uint32_t b = c->fb[a];
+                const float* pb = c->bpos + 3 * (size_t)b;
+                float diff[3] = {pi[0] - pb[0], pi[1] - pb[1], pi[2] - pb[2]};
+                float distance = dist3(pi, pb);
+                float g[3];
+                k_grad(&k, diff, distance, g);
+                float s = inv_rho0 * (c->lambda[i] + c->blambda[b]);
+                np[0] += s * g[0]; np[1] += s * g[1]; np[2] += s * g[2];
+            }
         if (c->P.container_enabled) {
             for (int a = 0; a < 3; ++a) {
                 if (np[a] < c->P.container_min[a]) np[a] = c->P.container_min[a];

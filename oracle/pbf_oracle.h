@@ -34,6 +34,13 @@ int orc_set_threads(orc_ctx* ctx, int num_threads); /* reference: num_threads(8)
 int orc_upload(orc_ctx* ctx, const float* pos, const float* vel, const float* mass,
                float uniform_mass, uint32_t n);
 int orc_set_colliders(orc_ctx* ctx, const pbf_collider* colliders, uint32_t count);
+/* static boundary particles (cuda_simulation.cu K5/K7/K9 and the boundary halves of K6/K8/K10,
+ * in the CPU path's arithmetic; PARITY UNPINNED); nb = 0 removes them */
+int orc_set_boundary(orc_ctx* ctx, const float* pos, const float* mass, float uniform_mass, uint32_t nb);
+int orc_get_boundary(orc_ctx* ctx, float* volume, float* density, float* lambda);
+int orc_get_boundary_neighbors(orc_ctx* ctx, uint32_t* fluid_counts, uint32_t* fluid_to_boundary,
+                               uint32_t stride_f, uint32_t* boundary_counts,
+                               uint32_t* boundary_to_fluid, uint32_t stride_b);
 int orc_set_solver_iterations(orc_ctx* ctx, int32_t iterations);
 int orc_set_gravity(orc_ctx* ctx, float gx, float gy, float gz);
 

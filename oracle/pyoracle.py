@@ -48,6 +48,9 @@ def load():
     lib.orc_upload.argtypes = [vp, vp, vp, vp, C.c_float, C.c_uint32]
     lib.orc_set_colliders.argtypes = [vp, C.POINTER(PbfCollider), C.c_uint32]
     lib.orc_set_solver_iterations.argtypes = [vp, C.c_int32]
+    lib.orc_set_boundary.argtypes = [vp, vp, vp, C.c_float, C.c_uint32]
+    lib.orc_get_boundary.argtypes = [vp, vp, vp, vp]
+    lib.orc_get_boundary_neighbors.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32]
     lib.orc_set_gravity.argtypes = [vp, C.c_float, C.c_float, C.c_float]
     for name in ("orc_predict_positions", "orc_collision_detection", "orc_compute_correction",
                  "orc_apply_solver_results", "orc_step"):
@@ -172,6 +175,27 @@ class Oracle:
 
     def set_colliders(self, cols):
         self._ck(self.lib.orc_set_colliders(self._h, collider_array(cols), len(cols)))
+
+    def set_boundary(self, pos, mass=None, uniform_mass: float = 1.0):
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+        nb = pos.shape[0]
+        mass = None if mass is None else np.ascontiguousarray(mass, dtype=np.float32).reshape(nb)
+        self._ck(self.lib.orc_set_boundary(self._h, _ptr(pos), _ptr(mass), C.c_float(uniform_mass), nb))
+        self.nb = nb
+
+    def boundary(self):
+        """(volume, density, lambda) of the boundary particles"""
+        out = [np.zeros(self.nb, np.float32) for _ in range(3)]
+        self._ck(self.lib.orc_get_boundary(self._h, *[_ptr(a) for a in out]))
+        return tuple(out)
+
+    def boundary_neighbors(self, stride_f=64, stride_b=64):
+        """(fluid counts, fluid->boundary lists, boundary counts, boundary->fluid lists)"""
+        fc, fl = np.zeros(self.n, np.uint32), np.zeros((self.n, stride_f), np.uint32)
+        bc, bl = np.zeros(self.nb, np.uint32), np.zeros((self.nb, stride_b), np.uint32)
+        self._ck(self.lib.orc_get_boundary_neighbors(self._h, _ptr(fc), _ptr(fl), stride_f,
+                                                     _ptr(bc), _ptr(bl), stride_b))
+        return fc, fl, bc, bl
 
     def set_solver_iterations(self, it):
         self._ck(self.lib.orc_set_solver_iterations(self._h, it))

@@ -35,10 +35,14 @@ CASES = {
     "c1_mass_aabb_6x8x6_3steps": {"scene": "c1", "dims": [6, 8, 6], "iters": 3, "steps": 3,
                                   "random_vel": 40.0, "random_mass": True,
                                   "aabb": [[0.6, 1.2, -9.6], [1.9, 2.7, -8.2]]},
+    # block held by boundary-particle walls only (no planes, no clamp)
+    "btank_10x10x8_6steps": {"scene": "btank", "dims": [10, 10, 8], "iters": 4, "steps": 6},
 }
 
 
 def scene_of(meta):
+    if meta["scene"] == "btank":
+        return scenes.boundary_tank(*meta["dims"], iterations=meta["iters"])[:4]
     if meta["scene"] == "c1":
         p, pos, mass, cols = scenes.c1_lattice(*meta["dims"], iterations=meta["iters"])
     else:
@@ -71,6 +75,9 @@ def build_case(meta, vel=None, masses=None, backend="oracle"):
         s = PbfContext(p, device=0)
     s.upload(pos, vel=vel, mass=masses, uniform_mass=mass)
     s.set_colliders(cols)
+    if meta["scene"] == "btank":
+        bpos, bmass = scenes.boundary_tank(*meta["dims"], iterations=meta["iters"])[4:]
+        s.set_boundary(bpos, uniform_mass=bmass)
     return s, meta["steps"]
 
 
@@ -87,6 +94,8 @@ def main():
             extra["vel0"] = vel
         if masses is not None:
             extra["mass0"] = masses
+        if meta["scene"] == "btank":
+            extra["bvol"], _, extra["blambda"] = o.boundary()
         np.savez_compressed(HERE / f"{name}.npz", meta=json.dumps(meta), pos=opos, vel=ovel,
                             rest_density=np.float32(o.rest_density()), **extra)
         print(name, pos.shape[0], "particles", steps, "steps ->",

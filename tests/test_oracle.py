@@ -272,3 +272,96 @@ def test_oracle_reproduces_golden(name):
     pos, vel, _, _ = o.download()
     assert np.array_equal(pos, z["pos"]) and np.array_equal(vel, z["vel"])
     assert np.float32(o.rest_density()) == z["rest_density"]
+
+
+# ------------------------------------------------------------------ boundary particles (8(f) rank 1)
+
+def _btank(nx=6, ny=6, nz=5, iters=2):
+    from fluidsimulation_amd import scenes
+    from oracle import pyoracle
+    p, pos, mass, cols, bpos, bm = scenes.boundary_tank(nx, ny, nz, iterations=iters)
+    o = pyoracle.Oracle(p)
+    o.upload(pos, uniform_mass=mass)
+    o.set_colliders(cols)
+    o.set_boundary(bpos, uniform_mass=bm)
+    return p, pos, mass, bpos, bm, o
+
+
+def test_boundary_volume_matches_closed_form():
+    """K5 (cuda_simulation.cu:331-374): V_b = m / (m W(0) + sum m W(r)); an interior particle of a
+    flat one-layer lattice at spacing d sees the 2-D lattice sum"""
+    from fluidsimulation_amd import scenes
+    p, pos, mass, bpos, bm, o = _btank(10, 4, 10)
+    vol, _, _ = o.boundary()
+    h, r, _, _, _ = scenes.sim_params_constants()
+    d, h = 2.0 * float(r), float(h)
+    coef = 315.0 / (64.0 * 3.1415926 * h ** 9)
+    s = 0.0
+    for a in range(-3, 4):
+        for b in range(-3, 4):
+            rr = d * d * (a * a + b * b)
+            if rr <= h * h:
+                s += coef * (h * h - rr) ** 3
+    expect = 1.0 / s
+    # floor particles far from every wall
+    c = bpos.mean(axis=0)
+    floor = np.where((bpos[:, 1] == bpos[:, 1].min()) & (np.abs(bpos[:, 0] - c[0]) < 2 * d)
+                     & (np.abs(bpos[:, 2] - c[2]) < 2 * d))[0]
+    assert floor.size >= 4
+    assert np.allclose(vol[floor], expect, rtol=2e-5)
+    assert np.all(vol > 0) and np.all(vol <= vol[floor].max() * 2.5)
+
+
+def test_boundary_tables_equal_brute_force():
+    """fluid->boundary and boundary->fluid rows: members = all pairs with dist2 <= h*h (fp32,
+    glm order), ordered by the 27-cell sweep (x outermost, z innermost) then index"""
+    p, pos, mass, bpos, bm, o = _btank(6, 6, 5)
+    o.predict_positions(DT); o.collision_detection(DT); o.spatial_search()
+    _, _, pred, _ = o.download()
+    fc, fl, bc, bl = o.boundary_neighbors(64, 64)
+    hh = np.float32(p.effective_radius) * np.float32(p.effective_radius)
+    sp = np.float32(p.grid_spacing)
+    fcell = np.floor(pred / sp).astype(np.int64)
+    bcell = np.floor(bpos / sp).astype(np.int64)
+
+    def d2(q, t):
+        v = (t - q).astype(np.float32)
+        return (v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2]
+
+    def expect(q, qcell, t, tcell):
+        m = np.where(d2(q, t) <= hh)[0]
+        rel = tcell[m] - qcell
+        assert np.all(np.abs(rel) <= 1)
+        order = np.lexsort((m, rel[:, 2], rel[:, 1], rel[:, 0]))
+        return m[order]
+
+    for i in range(pos.shape[0]):
+        e = expect(pred[i], fcell[i], bpos, bcell)
+        assert fc[i] == e.size and np.array_equal(fl[i, :fc[i]], e)
+    for b in range(bpos.shape[0]):
+        e = expect(bpos[b], bcell[b], pred, fcell)
+        assert bc[b] == e.size and np.array_equal(bl[b, :bc[b]], e)
+    assert fc.max() > 0 and bc.max() > 0
+
+
+def test_boundary_walls_hold_the_block():
+    p, pos, mass, bpos, bm, o = _btank(8, 8, 6, iters=4)
+    for _ in range(150):
+        o.step(DT)
+    q, v, _, _ = o.download()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    assert q[:, 1].min() > -0.02 and q[:, 0].min() > -0.03 and q[:, 2].min() > -0.03
+    _, dens, lam = o.boundary()
+    assert dens.max() > 0 and np.abs(lam).max() > 0
+
+
+def test_boundary_removed_equals_never_set():
+    from fluidsimulation_amd import scenes
+    from oracle import pyoracle
+    p, pos, mass, bpos, bm, o = _btank(5, 5, 5)
+    o.set_boundary(np.zeros((0, 3), np.float32))
+    o2 = pyoracle.Oracle(p)
+    o2.upload(pos, uniform_mass=mass)
+    for _ in range(3):
+        o.step(DT); o2.step(DT)
+    assert np.array_equal(o.download()[0], o2.download()[0])

@@ -342,16 +342,31 @@ class SlabGroup:
             b.build()
         viscous = B[0].viscous
         # with a second ghost layer the local sweeps give the inner layer's lambda / omega
-        local_ghost_sweeps = B[0].ghost_layers >= 2
+        L = B[0].ghost_layers
+        local_ghost_sweeps = L >= 2
+        # Communication-avoiding halo: a solver iteration on stale ghosts is still exact for the
+        # ghost layers that have all their neighbours' data -- lambda needs positions one cell
+        # further out, delta-p needs lambda one cell further out again -- so every iteration
+        # uses up two of the `valid` layers, and the ghost positions are refreshed from their
+        # owners only when fewer than two valid layers are left (L = 2: every iteration;
+        # L = 4: every other; L >= 2 * iterations: never).
+        valid = L
         for it in range(self.iterations):
+            if local_ghost_sweeps and valid < 2:
+                self._halo(HALO_PRED_LAMBDA)
+                valid = L
             for b in B:
                 b.lambda_pass(dt)
             if not local_ghost_sweeps:
                 self._halo(HALO_PRED_LAMBDA)
             for b in B:
                 b.delta_pass(dt)
-            if it + 1 < self.iterations or viscous:
+            if local_ghost_sweeps:
+                valid -= 2
+            elif it + 1 < self.iterations:
                 self._halo(HALO_PRED_LAMBDA)
+        if viscous:
+            self._halo(HALO_PRED_LAMBDA)
         # the velocity update also runs over the ghosts: their old and (refreshed) new positions
         # are both here, so v = (new - old) / dt needs no exchange
         for b in B:
@@ -374,7 +389,7 @@ class SlabGroup:
         """Moves the slab planes one cell towards balance (call between sub-steps, with the
         owned counts of ALL slabs); the next split migrates the particles of the moved plane.
         Returns the new planes."""
-        new = shift_planes(planes, counts, tolerance)
+        new = shift_planes(planes, counts, tolerance, min_width=2 * self.backends[0].ghost_layers)
         if new != list(planes):
             first = getattr(self.exchange, "rank", 0)
             for k, b in enumerate(self.backends):
@@ -400,7 +415,8 @@ def populate(backend, pos, mass, ids, planes_lo, planes_hi, spacing, vel=None):
     return int(m.sum())
 
 
-def rank_local_params(params: PbfParams, pos, planes, rank, world, headroom=1.5):
+def rank_local_params(params: PbfParams, pos, planes, rank, world, headroom=1.5,
+                      ghost_layers=GHOST_LAYERS):
     """This rank's pbf_params: capacity for its share (+ headroom for drift and ghosts) and a
     rank-local cell grid that only spans the slab's x range (+ ghost planes and a migration
     margin).  The wrap-around key makes the x extent of the global scene irrelevant to a rank,
@@ -416,12 +432,13 @@ def rank_local_params(params: PbfParams, pos, planes, rank, world, headroom=1.5)
         x_min, x_max = int(cx.min()), int(cx.max())
     lo = max(planes[rank], x_min) if planes[rank] != INT32_MIN else x_min
     hi = min(planes[rank + 1], x_max + 1) if planes[rank + 1] != INT32_MAX else x_max + 1
-    width = max(hi - lo, 1) + 8
+    margin = ghost_layers + 2          # ghost planes + migration / re-balancing drift
+    width = max(hi - lo, 1) + 2 * margin
     gx = 16
     while gx < width:
         gx *= 2
     p.grid_dim[0] = min(gx, int(params.grid_dim[0]))
-    p.grid_origin_cell[0] = lo - 4
+    p.grid_origin_cell[0] = lo - margin
     return p
 
 
@@ -429,12 +446,14 @@ class SlabSimulation:
     """What bench.py and multi-GPU callers use: this rank's slab of a scene, over RCCL."""
 
     def __init__(self, params: PbfParams, pos, mass, colliders, rank, world, device=0, vel=None,
-                 headroom=1.5, rebalance_every=0):
+                 headroom=1.5, rebalance_every=0, ghost_layers=GHOST_LAYERS):
         import torch.distributed as dist
-        planes = split_planes(pos, params.grid_spacing, world)
+        planes = split_planes(pos, params.grid_spacing, world, min_width=2 * ghost_layers)
         self.planes = planes
-        p = rank_local_params(params, pos, planes, rank, world, headroom)
-        self.backend = HipSlabBackend(p, colliders, mass, planes[rank], planes[rank + 1], device=device)
+        self.ghost_layers = ghost_layers
+        p = rank_local_params(params, pos, planes, rank, world, headroom, ghost_layers)
+        self.backend = HipSlabBackend(p, colliders, mass, planes[rank], planes[rank + 1], device=device,
+                                      ghost_layers=ghost_layers)
         ids = np.arange(pos.shape[0], dtype=np.uint32)
         self.n_initial = populate(self.backend, pos, mass, ids, planes[rank], planes[rank + 1],
                                   params.grid_spacing, vel=vel)

@@ -17,8 +17,8 @@ def slab_scene(nx=20, ny=6, nz=6, iterations=3, xsph_c=0.0, vorticity_eps=0.0, s
     return p, pos, mass, cols, vel
 
 
-def build_local_group(make_backend, p, pos, mass, cols, vel, world):
-    planes = split_planes(pos, p.grid_spacing, world)
+def build_local_group(make_backend, p, pos, mass, cols, vel, world, ghost_layers=2):
+    planes = split_planes(pos, p.grid_spacing, world, min_width=2 * ghost_layers)
     ids = np.arange(pos.shape[0], dtype=np.uint32)
     backends = []
     counts = []

@@ -51,6 +51,28 @@ def test_hip_slabs_with_viscosity(layers):
     assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
 
 
+@pytest.mark.parametrize("layers,viscous", [(4, False), (6, False), (4, True), (8, False)])
+def test_hip_deep_ghost_layers_skip_halo_refreshes(layers, viscous):
+    """communication-avoiding halo (slab.py): ghost positions are refreshed only when fewer than
+    two valid ghost layers are left; results stay bit-identical with the single domain"""
+    kw = dict(xsph_c=0.01, vorticity_eps=2e-6, vel_scale=2.0) if viscous else {}
+    its = 4 if layers == 8 else 3
+    p, pos, mass, cols, vel = slab_scene(nx=64 if layers == 8 else 48, ny=5, nz=5, iterations=its, **kw)
+    make = lambda p, cols, mass, lo, hi: hip_backend(p, cols, mass, lo, hi, ghost_layers=layers)
+    group, _ = build_local_group(make, p, pos, mass, cols, vel, 2, ghost_layers=layers)
+    calls = []
+    halo = group._halo
+    group._halo = lambda what: (calls.append(what), halo(what))[1]
+    steps = 5
+    for _ in range(steps):
+        group.step(DT)
+    expect = {4: 1, 6: 0, 8: 0}[layers] + (1 if viscous else 0)
+    assert sum(1 for w in calls if w == 0) == expect * steps
+    ids, gpos, gvel = group.export()
+    opos, ovel = single_domain_oracle(p, pos, mass, cols, vel, steps)
+    assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
+
+
 def test_hip_slabs_larger_block_vs_single_gpu_ctx():
     """40x20x20 = 16 000 particles in 4 slabs against ONE ctx stepping the whole scene."""
     from fluidsimulation_amd import PbfContext

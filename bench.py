@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2, help="oracle sub-steps to time (0 = skip)")
     ap.add_argument("--cpu-block", type=int, nargs=3, default=None)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--ghost-layers", type=int, default=4)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with several ranks sharing one GPU "
                          "(payloads staged through the host); numbers from it are not bench results")
@@ -135,14 +136,18 @@ def main():
         from fluidsimulation_amd.slab import SlabSimulation
         # weak scaling: every rank brings one block; slabs along x
         p, pos, mass, cols = scenes.dam_break(block[0] * world, block[1], block[2], iterations=a.iters)
-        sim = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local)
+        # ghost_layers = 4: one halo refresh per sub-step instead of three (slab.py, "communication-
+        # avoiding halo"); transport: grouped ncclSend/ncclRecv from the C-ABI library when the
+        # group runs on nccl (torch.distributed stays the bootstrap and the fallback)
+        sim = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local,
+                             ghost_layers=a.ghost_layers)
         n_total = pos.shape[0]
         stepper = sim.step
         syncer = sim.sync
         ctx = sim.ctx
         workload = (f"{block[0] * world}x{block[1]}x{block[2]} dam-break block ({n_total} particles) in "
                     f"{world} x-slabs, {a.iters} solver iterations, dt=5e-4")
-        parallelism = f"slab{world}"
+        parallelism = f"slab{world}, {a.ghost_layers} ghost layers, transport {sim.transport}"
 
     def barrier():
         syncer()

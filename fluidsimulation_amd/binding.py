@@ -35,6 +35,13 @@ class PbfCollider(C.Structure):
     _fields_ = [("type", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("d", C.c_float)]
 
 
+PBF_COMM_ID_BYTES = 128
+
+
+class PbfP2P(C.Structure):
+    _fields_ = [("send", C.c_int32), ("peer", C.c_int32), ("buf", C.c_void_p), ("bytes", C.c_uint64)]
+
+
 class PbfParams(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32),
@@ -159,6 +166,8 @@ SYMBOLS = [
     "pbf_slab_pack_halo", "pbf_slab_unpack_halo", "pbf_slab_export", "pbf_selftest_sqrt",
     "pbf_set_boundary", "pbf_num_boundary_particles", "pbf_get_boundary",
     "pbf_get_boundary_neighbors",
+    "pbf_comm_unique_id", "pbf_comm_create", "pbf_comm_destroy", "pbf_comm_rank", "pbf_comm_world",
+    "pbf_comm_last_error", "pbf_comm_batch", "pbf_slab_halo_exchange",
 ]
 
 _lib = None
@@ -233,6 +242,17 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_slab_unpack_halo.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp, C.c_uint32]
     lib.pbf_slab_export.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.pbf_selftest_sqrt.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    lib.pbf_comm_unique_id.argtypes = [vp]
+    lib.pbf_comm_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.pbf_comm_destroy.argtypes = [vp]
+    lib.pbf_comm_rank.argtypes = [vp]
+    lib.pbf_comm_rank.restype = C.c_int32
+    lib.pbf_comm_world.argtypes = [vp]
+    lib.pbf_comm_world.restype = C.c_int32
+    lib.pbf_comm_last_error.argtypes = [vp]
+    lib.pbf_comm_last_error.restype = C.c_char_p
+    lib.pbf_comm_batch.argtypes = [vp, vp, C.POINTER(PbfP2P), C.c_uint32]
+    lib.pbf_slab_halo_exchange.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.pbf_set_boundary.argtypes = [vp, vp, vp, C.c_float, C.c_uint32, C.c_uint32]
     lib.pbf_num_boundary_particles.argtypes = [vp]
     lib.pbf_num_boundary_particles.restype = C.c_uint32
@@ -245,6 +265,51 @@ def load_library(path: os.PathLike | None = None):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class RcclComm:
+    """One rank of an RCCL communicator behind the C ABI (pbf_comm_*).  `unique_id()` on rank 0,
+    the 128 bytes travel to the other ranks by any means, then every rank constructs."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int = -1):
+        self.lib = load_library()
+        assert len(unique_id) == PBF_COMM_ID_BYTES
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), PBF_COMM_ID_BYTES)
+        rc = self.lib.pbf_comm_create(buf, rank, world, device, C.byref(self._h))
+        if rc != PBF_OK:
+            raise PbfError(rc, (self.lib.pbf_comm_last_error(None) or b"pbf_comm_create failed").decode())
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = load_library()
+        buf = C.create_string_buffer(PBF_COMM_ID_BYTES)
+        rc = lib.pbf_comm_unique_id(buf)
+        if rc != PBF_OK:
+            raise PbfError(rc, (lib.pbf_comm_last_error(None) or b"pbf_comm_unique_id failed").decode())
+        return buf.raw
+
+    def batch(self, ops, stream: int = 0):
+        """ops: (send: bool, peer: int, device pointer: int, bytes: int), one grouped exchange,
+        asynchronous on `stream` (a hipStream_t handle)"""
+        arr = (PbfP2P * max(1, len(ops)))()
+        for i, (snd, peer, ptr, nbytes) in enumerate(ops):
+            arr[i].send, arr[i].peer, arr[i].buf, arr[i].bytes = int(bool(snd)), int(peer), ptr or None, int(nbytes)
+        rc = self.lib.pbf_comm_batch(self._h, C.c_void_p(stream or None), arr, len(ops))
+        if rc != PBF_OK:
+            raise PbfError(rc, self.lib.pbf_comm_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h:
+            self.lib.pbf_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PbfContext:
@@ -448,6 +513,12 @@ class PbfContext:
     def slab_unpack_halo(self, what: int, d_left: int, count_left: int, d_right: int, count_right: int):
         self._ck(self.lib.pbf_slab_unpack_halo(self._h, what, C.c_void_p(d_left or None), count_left,
                                                C.c_void_p(d_right or None), count_right))
+
+    def slab_halo_exchange(self, comm: "RcclComm", what: int, left: int, right: int, d_send_left: int,
+                           d_send_right: int, d_recv_left: int, d_recv_right: int):
+        self._ck(self.lib.pbf_slab_halo_exchange(self._h, comm._h, what, left, right,
+                                                 C.c_void_p(d_send_left or None), C.c_void_p(d_send_right or None),
+                                                 C.c_void_p(d_recv_left or None), C.c_void_p(d_recv_right or None)))
 
     def slab_export(self, d_records: int, max_records: int) -> int:
         k = C.c_uint32()

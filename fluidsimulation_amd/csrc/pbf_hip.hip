@@ -2477,6 +2477,26 @@ int pbf_slab_unpack_halo(pbf_ctx* c, int32_t what, const void* d_from_left, uint
     return PBF_OK;
 }
 
+int pbf_slab_halo_exchange(pbf_ctx* c, pbf_comm* comm, int32_t what, int32_t left_rank,
+                           int32_t right_rank, void* d_send_left, void* d_send_right,
+                           void* d_recv_left, void* d_recv_right) {
+    ENTER(c);
+    if (!comm) return fail(c, PBF_ERR_INVALID, "null communicator");
+    const uint32_t s0 = c->bcount[0], s1 = c->bcount[1], r0 = c->ghost_count[0], r1 = c->ghost_count[1];
+    if ((left_rank < 0 && (s0 || r0)) || (right_rank < 0 && (s1 || r1)))
+        return fail(c, PBF_ERR_INVALID, "boundary particles / ghosts on an open end");
+    if ((r0 && !d_recv_left) || (r1 && !d_recv_right)) return fail(c, PBF_ERR_INVALID, "null buffer");
+    int rc = pbf_slab_pack_halo(c, what, d_send_left, d_send_right);
+    if (rc) return rc;
+    // receives first: a rank whose two neighbours are the same rank (world 2 is not periodic, but a
+    // rehearsal on one rank is) still pairs message k with message k
+    pbf_p2p ops[4] = {{1, left_rank, d_send_left, (uint64_t)s0 * 16}, {0, left_rank, d_recv_left, (uint64_t)r0 * 16},
+                      {1, right_rank, d_send_right, (uint64_t)s1 * 16}, {0, right_rank, d_recv_right, (uint64_t)r1 * 16}};
+    rc = pbf_comm_batch(comm, (void*)c->stream, ops, 4);
+    if (rc) return fail(c, rc, std::string("halo exchange: ") + pbf_comm_last_error(comm));
+    return pbf_slab_unpack_halo(c, what, d_recv_left, r0, d_recv_right, r1);
+}
+
 int pbf_slab_export(pbf_ctx* c, void* d_records, uint32_t max_records, uint32_t* count) {
     ENTER(c);
     if (!count) return fail(c, PBF_ERR_INVALID, "null count");

@@ -288,6 +288,36 @@ int pbf_slab_unpack_halo(pbf_ctx* ctx, int32_t what, const void* d_from_left, ui
 /* all owned particles as records, arbitrary order (synchronises) */
 int pbf_slab_export(pbf_ctx* ctx, void* d_records, uint32_t max_records, uint32_t* count);
 
+/* ---- RCCL transport of the slab exchange (no counterpart in the reference).
+ * One pbf_comm = one rank of an RCCL communicator; RCCL is bound at run time (librccl.so.1), so
+ * nothing here is needed on a single GPU.  Bootstrap: rank 0 calls pbf_comm_unique_id and hands
+ * the PBF_COMM_ID_BYTES bytes to every rank by any means (torch.distributed, a file, MPI);
+ * every rank then calls pbf_comm_create (collective: returns when all `world` ranks joined). */
+#define PBF_COMM_ID_BYTES 128
+typedef struct pbf_comm pbf_comm;
+typedef struct pbf_p2p {
+    int32_t  send;   /* 1 = ncclSend, 0 = ncclRecv */
+    int32_t  peer;   /* rank */
+    void*    buf;    /* device pointer */
+    uint64_t bytes;  /* 0 = skipped on both ends (sizes are agreed beforehand) */
+} pbf_p2p;
+int pbf_comm_unique_id(void* id_out);
+int pbf_comm_create(const void* id, int32_t rank, int32_t world, int32_t device, pbf_comm** out);
+int pbf_comm_destroy(pbf_comm* comm);
+int32_t pbf_comm_rank(const pbf_comm* comm);
+int32_t pbf_comm_world(const pbf_comm* comm);
+const char* pbf_comm_last_error(const pbf_comm* comm);
+/* one ncclGroupStart .. ncclGroupEnd of sends / receives, enqueued on hip_stream (hipStream_t):
+ * asynchronous, ordered with the kernels of a ctx that runs on the same stream.  Messages
+ * between one pair of ranks match in the order they are listed. */
+int pbf_comm_batch(pbf_comm* comm, void* hip_stream, const pbf_p2p* ops, uint32_t n_ops);
+/* one halo refresh in one call, on the ctx stream: pbf_slab_pack_halo into d_send_*, one grouped
+ * exchange with the slab neighbours (rank < 0 = open end), pbf_slab_unpack_halo from d_recv_*.
+ * Buffers: one float4 per boundary-plane particle / per ghost. */
+int pbf_slab_halo_exchange(pbf_ctx* ctx, pbf_comm* comm, int32_t what, int32_t left_rank,
+                           int32_t right_rank, void* d_send_left, void* d_send_right,
+                           void* d_recv_left, void* d_recv_right);
+
 /* self-test (no reference counterpart): compares the kernels' 6-instruction correctly rounded
  * fp32 square root with the compiler's sqrtf over EVERY non-negative float; *mismatches must
  * be 0 (first_bad = bit pattern of the first differing input, 0xffffffff if none) */

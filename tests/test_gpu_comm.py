@@ -1,0 +1,100 @@
+"""GPU: the C-ABI RCCL transport (pbf_comm_*) on the one GPU of the test box.  A communicator of
+one rank can still send to itself inside a group, which exercises the real ncclSend / ncclRecv
+path (binding, stream ordering, byte counts); the left/right protocol logic above it is covered
+on CPU over a transport with NCCL's matching rule (tests/test_slab_cpu.py) and the multi-rank
+run itself by bench.py --gpus N on the multi-GPU node."""
+import numpy as np
+import pytest
+
+from fluidsimulation_amd import PbfContext, scenes
+from fluidsimulation_amd.binding import PbfError, RcclComm
+
+pytestmark = pytest.mark.gpu
+DT = 0.0005
+
+
+def test_self_send_recv_moves_the_bytes_in_order():
+    import torch
+    comm = RcclComm(RcclComm.unique_id(), 0, 1, 0)
+    s = torch.cuda.current_stream().cuda_stream
+    a = torch.arange(1000, dtype=torch.float32, device="cuda")
+    b = torch.arange(5000, 5300, dtype=torch.float32, device="cuda")
+    ra, rb = torch.zeros_like(a), torch.zeros_like(b)
+    empty = torch.zeros(0, device="cuda")
+    comm.batch([(True, 0, a.data_ptr(), a.numel() * 4), (False, 0, ra.data_ptr(), ra.numel() * 4),
+                (True, 0, empty.data_ptr(), 0), (False, 0, 0, 0),
+                (True, 0, b.data_ptr(), b.numel() * 4), (False, 0, rb.data_ptr(), rb.numel() * 4)], s)
+    torch.cuda.synchronize()
+    assert torch.equal(a, ra) and torch.equal(b, rb)
+    with pytest.raises(PbfError):
+        comm.batch([(True, 3, a.data_ptr(), 16)], s)    # peer out of range
+    comm.close()
+
+
+def test_world1_slab_over_rccl_equals_single_ctx():
+    """the slab pipeline with the RCCL exchange object and no neighbours"""
+    import torch
+    from fluidsimulation_amd import slab as S
+    p, pos, mass, cols = scenes.dam_break(16, 12, 10, iterations=3)
+    comm = RcclComm(RcclComm.unique_id(), 0, 1, 0)
+    q = S.rank_local_params(p, pos, [S.INT32_MIN, S.INT32_MAX], 0, 1)
+    b = S.HipSlabBackend(q, cols, mass, S.INT32_MIN, S.INT32_MAX, device=0)
+    S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), S.INT32_MIN, S.INT32_MAX, p.grid_spacing)
+    grp = S.SlabGroup([b], S.P2PExchange(comm, 0, 1), 3)
+    g = PbfContext(p, device=0)
+    g.upload(pos, uniform_mass=mass)
+    g.set_colliders(cols)
+    for _ in range(5):
+        grp.step(DT)
+        g.step(DT)
+    ids, gpos, gvel = grp.export()
+    pos1, vel1, _ = g.download()
+    assert np.array_equal(gpos, pos1) and np.array_equal(gvel, vel1)
+
+
+def test_fused_halo_exchange_mirrors_the_boundary_planes():
+    """pbf_slab_halo_exchange = pack -> grouped send/recv -> unpack, against the three separate
+    calls; the slab's own boundary planes come back as its ghosts (rank 0 is its own neighbour)"""
+    import torch
+    from fluidsimulation_amd import slab as S
+    p, pos, mass, cols = scenes.dam_break(24, 8, 8, iterations=2)
+    p.max_neighbors = 128
+    cx = S.cell_x(pos[:, 0], p.grid_spacing)
+    lo, hi = int(cx.min()), int(cx.max()) + 1
+    comm = RcclComm(RcclComm.unique_id(), 0, 1, 0)
+
+    def slab():
+        q = S.rank_local_params(p, pos, [S.INT32_MIN, S.INT32_MAX], 0, 1)
+        b = S.HipSlabBackend(q, cols, mass, lo, hi, device=0)
+        S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), lo, hi, p.grid_spacing)
+        b.predict(DT)
+        b.split_launch()
+        own = [int(v) for v in b.count_tensor().cpu().tolist()]
+        (ml, gl), (mr, gr) = b.split_finish(own)
+        assert own[3] > 0 and own[5] > 0 and own[2] == 0 and own[4] == 0
+        tagged = []
+        for t in (gl, gr):
+            t = t.clone()
+            t[:, 7].view(torch.int32).bitwise_or_(0x40000000)
+            tagged.append(t)
+        b.append_owned(ml, mr)
+        b.append_ghosts(tagged[0], tagged[1])
+        b.build()
+        b.lambda_pass(DT)
+        b.delta_pass(DT)
+        return b
+
+    a, b = slab(), slab()
+    # separate calls, in-process hand-off
+    sl, sr = a.halo_pack(0)
+    a.halo_unpack(0, sl.clone(), sr.clone())
+    # one fused call over RCCL
+    ex = S.P2PExchange(comm, 0, 1)
+    ex.left = ex.right = 0
+    assert ex.halo_fused(b, 0)
+    for s in (a, b):
+        s.lambda_pass(DT); s.delta_pass(DT); s.finalize_stage(0, DT)
+    ra, rb = a.export(), b.export()
+    oa, ob = np.argsort(S.record_ids(ra)), np.argsort(S.record_ids(rb))
+    assert np.array_equal(ra[oa], rb[ob])
+    assert np.isfinite(ra).all()

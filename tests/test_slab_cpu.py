@@ -158,3 +158,65 @@ def test_gloo_world2_equals_single_domain(tmp_path):
     assert np.array_equal(ids[order], np.arange(pos.shape[0]))
     assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
     assert all(z["ids"].size > 0 for z in parts)
+
+
+class _FakeComm:
+    """In-process stand-in for binding.RcclComm with NCCL's matching rule: the k-th send from a
+    to b pairs with b's k-th receive from a.  Threads play the ranks."""
+
+    def __init__(self, rank, queues):
+        self.rank, self.q = rank, queues
+
+    def batch(self, ops, stream=0):
+        import ctypes
+        for snd, peer, ptr, nbytes in ops:
+            if snd and nbytes:
+                self.q[(self.rank, peer)].put(ctypes.string_at(ptr, nbytes))
+        for snd, peer, ptr, nbytes in ops:
+            if not snd and nbytes:
+                data = self.q[(peer, self.rank)].get(timeout=60)
+                assert len(data) == nbytes, "message sizes disagree between the two ends"
+                ctypes.memmove(ptr, data, nbytes)
+
+
+@pytest.mark.parametrize("world,layers", [(2, 2), (3, 2), (3, 4)])
+def test_p2p_exchange_protocol_over_a_fake_rccl(world, layers):
+    """slab.P2PExchange (what runs over RCCL through the C ABI on the multi-GPU node) driven by
+    `world` threads over a transport with NCCL's ordering semantics, oracle backend: must equal
+    the single-domain run bit for bit"""
+    import queue
+    import threading
+    from fluidsimulation_amd.slab import P2PExchange, SlabGroup, populate, split_planes
+    from oracle.slab_backend import OracleSlabBackend
+    p, pos, mass, cols, vel = slab_scene(nx=60 if layers == 4 else 24, ny=5, nz=5)
+    steps = 5
+    planes = split_planes(pos, p.grid_spacing, world, min_width=2 * layers)
+    queues = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    out, errs = {}, []
+
+    def work(rank):
+        try:
+            b = OracleSlabBackend(p, cols, mass, planes[rank], planes[rank + 1], threads=1, ghost_layers=layers)
+            populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
+                     p.grid_spacing, vel=vel)
+            g = SlabGroup([b], P2PExchange(_FakeComm(rank, queues), rank, world), int(p.solver_iterations))
+            for _ in range(steps):
+                g.step(DT)
+            out[rank] = g.export()
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs
+    ids = np.concatenate([out[r][0] for r in range(world)])
+    order = np.argsort(ids)
+    gpos = np.concatenate([out[r][1] for r in range(world)])[order]
+    gvel = np.concatenate([out[r][2] for r in range(world)])[order]
+    opos, ovel = single_domain_oracle(p, pos, mass, cols, vel, steps)
+    assert np.array_equal(ids[order], np.arange(pos.shape[0]))
+    assert np.array_equal(gpos, opos) and np.array_equal(gvel, ovel)
+    assert all(q.empty() for q in queues.values())

@@ -109,6 +109,33 @@ __device__ __forceinline__ float grad_scalar_strict(const KernConsts& k, float d
     return 0.0f;
 }
 
+// Poly6_W and the Poly6 gradient scalar of one distance in one go: they share d*d, q and q*q and
+// ONE support test (a distance is a square root: >= 0 or NaN, and NaN fails `<= h` exactly like
+// it fails the reference's `d >= 0 && d <= h`).  Same values as poly6_strict +
+// grad_scalar_strict<PBF_GRAD_POLY6>.
+__device__ __forceinline__ void poly6_pair(const KernConsts& k, float distance, float& w, float& gs) {
+    const double d = (double)distance;
+    const double d2 = d * d;
+    const double q = k.h2 - d2;
+    const double q2 = q * q;
+    const double q3 = q2 * q;  // (q * q) * q
+    const float wv = (float)(k.w_coef * q3);
+    const float gv = k.g_coef * (float)q2;
+    const bool in = distance <= k.h;
+    w = in ? wv : 0.0f;
+    gs = in ? gv : 0.0f;
+}
+
+template <int GRAD>
+__device__ __forceinline__ void kernel_pair(const KernConsts& k, float distance, float& w, float& gs) {
+    if (GRAD == PBF_GRAD_POLY6) {
+        poly6_pair(k, distance, w, gs);
+    } else {
+        w = poly6_strict(k, distance);
+        gs = grad_scalar_strict<GRAD>(k, distance);
+    }
+}
+
 // Correctly rounded fp32 square root (glm::distance -> sqrtf).  The compiler's expansion of
 // sqrtf costs ~17 instructions (input scaling for subnormals, v_sqrt_f32, two-sided fix-up);
 // for inputs >= 2^-96 one rsq and one Markstein-style fma correction give the same bits in 5

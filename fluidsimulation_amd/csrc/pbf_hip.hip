@@ -735,8 +735,8 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __r
         float mj = UNIFORM_MASS ? uniform_mass : pos[j].w;
         float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
         float distance = sqrt_rn(dot3(dx, dy, dz, dx, dy, dz));
-        float w = poly6_strict(kc, distance);
-        float gs = grad_scalar_strict<GRAD>(kc, distance);
+        float w, gs;
+        kernel_pair<GRAD>(kc, distance, w, gs);
         dens += mj * w;
         // gradientC_j = (1/rho0) * (gs * diff); sum += dot(gC, gC)
         float gx = inv_rho0 * (gs * dx), gy = inv_rho0 * (gs * dy), gz = inv_rho0 * (gs * dz);
@@ -786,8 +786,9 @@ __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
     for_each_neighbor<SWEEP_BATCH>(i, nbr_count[i], nbr, cap, prd, [&](uint32_t, const float4& xj) {
         float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
         float distance = sqrt_rn(dot3(dx, dy, dz, dx, dy, dz));
-        float sc = scorr_strict(kc, poly6_strict(kc, distance));
-        float gs = grad_scalar_strict<GRAD>(kc, distance);
+        float w, gs;
+        kernel_pair<GRAD>(kc, distance, w, gs);
+        float sc = scorr_strict(kc, w);
         // result = (1/rho0) * (lambda_i + lambda_j + (float)scorr) * gradW
         float s = inv_rho0 * (xi.w + xj.w + sc);
         nx += s * (gs * dx);

@@ -54,10 +54,10 @@ def tank_planes(lo, hi):
 
 
 def _grid_dim_for(extent_cells):
-    d = 16
-    while d < extent_cells + 2:
-        d *= 2
-    return d
+    """cells along one axis: the extent plus one spare cell on either side (no fluid cell on a
+    grid face) and one for the partial last cell, rounded up to a multiple of 8.  The key wraps
+    with %, so no power of two is needed and the per-step scan only covers what the tank spans."""
+    return max(16, (int(extent_cells) + 3 + 7) // 8 * 8)
 
 
 def dam_break(nx, ny, nz, iterations=4, tank_x_factor=2.5, xsph_c=0.0, vorticity_eps=0.0,

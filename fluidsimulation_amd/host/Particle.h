@@ -13,7 +13,7 @@ public:
     ParticleSet(size_t n, float particle_mass)
         : m_size(n), m_positions(n), m_predict_positions(n), m_new_positions(n), m_velocity(n),
           m_force(n), m_mass(n, particle_mass), m_massInv(n, 1.f / particle_mass), m_density(n, 0.f),
-          m_C(n, 0.f), m_lambda(n, 0.f) {}
+          m_C(n, 0.f), m_lambda(n, 0.f), m_volume(n, 0.f) {}
 
     size_t m_size = 0;
     std::vector<Vec3> m_positions;
@@ -26,4 +26,5 @@ public:
     std::vector<float> m_density;
     std::vector<float> m_C;
     std::vector<float> m_lambda;
+    std::vector<float> m_volume;  // boundary particles: Akinci volume (Particle.h:68)
 };

@@ -17,6 +17,10 @@ public:
     // ParticleSystem.cpp:99-103
     ParticleSet* AllocateParticles(size_t n, float particle_mass);
     ParticleSet* getParticles() { return m_particles.get(); }
+    // ParticleSystem.cpp:105-109; the boundary set is uploaded by InitializeDevice
+    // (pbf_set_boundary: the reference's InitializeBoundaryCudaData, Simulation.cpp:492-526)
+    ParticleSet* AllocateBoundaryParticles(size_t n, float particle_mass);
+    ParticleSet* getBoundaryParticles() { return m_boundary_particles.get(); }
     void setParticleRadius(float r) { m_particle_radius = r; }
     float getParticleRadius() const { return m_particle_radius; }
 
@@ -56,6 +60,7 @@ public:
 
 private:
     std::unique_ptr<ParticleSet> m_particles;
+    std::unique_ptr<ParticleSet> m_boundary_particles;
     float m_particle_radius = 0.f;
     pbf_ctx* m_ctx = nullptr;
     std::string m_error;

@@ -14,6 +14,11 @@ ParticleSet* ParticleSystem::AllocateParticles(size_t n, float particle_mass) {
     return m_particles.get();
 }
 
+ParticleSet* ParticleSystem::AllocateBoundaryParticles(size_t n, float particle_mass) {
+    m_boundary_particles = std::make_unique<ParticleSet>(n, particle_mass);
+    return m_boundary_particles.get();
+}
+
 bool ParticleSystem::InitializeDevice(const pbf_params& params, int device) {
     if (!m_particles) {
         m_error = "AllocateParticles has not been called";
@@ -43,6 +48,19 @@ bool ParticleSystem::InitializeDevice(const pbf_params& params, int device) {
         m_error = pbf_last_error(m_ctx);
         return false;
     }
+    if (m_boundary_particles && m_boundary_particles->m_size) {
+        ParticleSet& b = *m_boundary_particles;
+        bool b_uniform = true;
+        for (size_t i = 1; i < b.m_size; ++i)
+            if (b.m_mass[i] != b.m_mass[0]) { b_uniform = false; break; }
+        rc = pbf_set_boundary(m_ctx, &b.m_positions[0].x, b_uniform ? nullptr : b.m_mass.data(),
+                              b.m_mass[0], (uint32_t)b.m_size, 0);
+        if (rc != PBF_OK) {
+            m_error = pbf_last_error(m_ctx);
+            return false;
+        }
+        pbf_get_boundary(m_ctx, b.m_volume.data(), nullptr, nullptr);
+    }
     return true;
 }
 
@@ -54,6 +72,10 @@ bool ParticleSystem::Update() {
     if (rc == PBF_OK) {
         s.m_predict_positions = s.m_new_positions;  // UpdatePredictPosition, Simulation.cpp:714-721
         rc = pbf_get_scalars(m_ctx, s.m_density.data(), s.m_C.data(), s.m_lambda.data());
+    }
+    if (rc == PBF_OK && m_boundary_particles && m_boundary_particles->m_size) {
+        ParticleSet& b = *m_boundary_particles;
+        rc = pbf_get_boundary(m_ctx, b.m_volume.data(), b.m_density.data(), b.m_lambda.data());
     }
     if (rc != PBF_OK) m_error = pbf_last_error(m_ctx);
     return rc == PBF_OK;

@@ -62,3 +62,25 @@ def test_headless_driver_resumes_from_a_snapshot(tmp_path):
     assert r.returncode == 0, r.stderr
     a, b = read_dump(d1), read_dump(d2)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_headless_driver_c2_scene_with_boundary_particles(tmp_path):
+    """--scene c2: the README CUDA scene built by the C++ facade (GenerateFluidCube +
+    InitializeBoundaryParticles restated in pbf_run.cpp, ParticleSystem::AllocateBoundaryParticles
+    -> pbf_set_boundary) == the Python generators + the oracle's boundary coupling"""
+    h, r, _, _, _ = scenes.sim_params_constants()
+    assert h == np.float32(0.041528303) and r == np.float32(0.012331058)
+    dump = tmp_path / "c2.bin"
+    res = subprocess.run([str(RUN), "--scene", "c2", "--steps", "3", "--iters", "4", "--dump", str(dump)],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    pos, vel, _ = read_dump(dump)
+    p, ipos, mass, cols, bpos, bm = scenes.c2_reference_cuda_scene(iterations=4)
+    assert pos.shape == ipos.shape
+    o = pyoracle.Oracle(p)
+    o.upload(ipos, uniform_mass=mass)
+    o.set_boundary(bpos, uniform_mass=bm)
+    for _ in range(3):
+        o.step(0.0005)
+    op, ov, _, _ = o.download()
+    assert np.array_equal(pos, op) and np.array_equal(vel, ov)

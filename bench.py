@@ -44,8 +44,8 @@ def pmc_traffic(kernel_phase):
     requests at half their size for wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM;
     calibrated on k_finalize: 32 MB read -> 16 MB counted), WRITE_SIZE is exact; both in KiB."""
     f = ROOT / "profiles" / "pmc_latest.json"
-    names = {"lambda": "k_lambda<true, 0>", "delta": "k_delta<0>", "predict": "k_predict",
-             "finalize": "k_finalize", "neighbors": "k_neighbors"}
+    names = {"lambda": "k_lambda<true, 0, false>", "delta": "k_delta<0, false>", "predict": "k_predict",
+             "finalize": "k_finalize", "neighbors": "k_neighbors<true>"}
     try:
         d = json.loads(f.read_text())
         k = d["kernels"][names[kernel_phase]]

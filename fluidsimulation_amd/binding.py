@@ -38,6 +38,19 @@ class PbfCollider(C.Structure):
 PBF_COMM_ID_BYTES = 128
 
 
+class PbfDemParams(C.Structure):
+    _fields_ = [("particle_radius", C.c_float), ("static_friction", C.c_float),
+                ("kinematic_friction", C.c_float), ("iterations", C.c_int32)]
+
+
+def dem_params(particle_radius, static_friction=1.0, kinematic_friction=0.75, iterations=3):
+    """SimParams' DEM constants (reference Simulation.cpp:335,349-350; iterations :148)"""
+    d = PbfDemParams()
+    d.particle_radius, d.static_friction = float(particle_radius), float(static_friction)
+    d.kinematic_friction, d.iterations = float(kinematic_friction), int(iterations)
+    return d
+
+
 class PbfP2P(C.Structure):
     _fields_ = [("send", C.c_int32), ("peer", C.c_int32), ("buf", C.c_void_p), ("bytes", C.c_uint64)]
 
@@ -167,7 +180,7 @@ SYMBOLS = [
     "pbf_set_boundary", "pbf_num_boundary_particles", "pbf_get_boundary",
     "pbf_get_boundary_neighbors",
     "pbf_comm_unique_id", "pbf_comm_create", "pbf_comm_destroy", "pbf_comm_rank", "pbf_comm_world",
-    "pbf_comm_last_error", "pbf_comm_batch", "pbf_slab_halo_exchange",
+    "pbf_comm_last_error", "pbf_comm_batch", "pbf_slab_halo_exchange", "pbf_step_dem",
 ]
 
 _lib = None
@@ -242,6 +255,7 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_slab_unpack_halo.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp, C.c_uint32]
     lib.pbf_slab_export.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.pbf_selftest_sqrt.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    lib.pbf_step_dem.argtypes = [vp, C.c_float, C.POINTER(PbfDemParams)]
     lib.pbf_comm_unique_id.argtypes = [vp]
     lib.pbf_comm_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.pbf_comm_destroy.argtypes = [vp]
@@ -408,6 +422,9 @@ class PbfContext:
 
     def step(self, dt):
         self._ck(self.lib.pbf_step(self._h, C.c_float(dt)))
+
+    def step_dem(self, dt, dem: "PbfDemParams"):
+        self._ck(self.lib.pbf_step_dem(self._h, C.c_float(dt), C.byref(dem)))
 
     def sync(self):
         self._ck(self.lib.pbf_sync(self._h))

@@ -958,6 +958,114 @@ __global__ __launch_bounds__(BLOCK) void k_boundary_unpack(const float4* __restr
     o_lam[o] = bprd[b].w;
 }
 
+// ------------------------------------------------------------------------------------
+// PBD granular / DEM solver (PARITY UNPINNED): solve_pbd_dem of the
+// reference's CUDA path (cuda_simulation.cu:1730-2225, dead code there) in plain fp32 on this
+// repo's sorted arrays.  One thread per particle sweeps the 27 cells around its CURRENT cell
+// (calcGridPos(pos), :1887) in z, y, x order over the buckets frozen at the sort; per-cell
+// partial sums are added to the total like the reference's `corr += pbd_*_correction(cell)`.
+// FRICTION = false: compute_distance_correction + apply_correction (:1867-1926,1466-1488);
+// FRICTION = true : compute_friction_correction + apply_correction (:2084-2156).
+
+struct DemConsts {
+    float two_r, mu_s, mu_k;
+};
+
+template <bool FRICTION>
+__device__ __forceinline__ void dem_term(const DemConsts& D, const float4& xi, const float4& oi,
+                                         const float4& xj, const float4& oj, bool moving, float w0,
+                                         float w1, float& ax, float& ay, float& az) {
+    const float vx = xi.x - xj.x, vy = xi.y - xj.y, vz = xi.z - xj.z;
+    const float dist = sqrt_rn(dot3(vx, vy, vz, vx, vy, vz));
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (dist <= D.two_r) {
+        const float w_sum = w0 + w1;
+        const float nx = vx / dist, ny = vy / dist, nz = vz / dist;
+        if (!FRICTION) {
+            const float C = dist - D.two_r;
+            const float s = -w0 * (1.f / w_sum) * C;
+            cx = s * nx;
+            cy = s * ny;
+            cz = s * nz;
+        } else {
+            const float penetration = D.two_r - dist;
+            float dx = xi.x - oi.x, dy = xi.y - oi.y, dz = xi.z - oi.z;
+            if (moving) {  // (predict0 - original0) + (predict1 - original1), :1978
+                dx = dx + (xj.x - oj.x);
+                dy = dy + (xj.y - oj.y);
+                dz = dz + (xj.z - oj.z);
+            }
+            const float dn = dot3(dx, dy, dz, nx, ny, nz);
+            float tx = dx - dn * nx, ty = dy - dn * ny, tz = dz - dn * nz;
+            const float threshold = D.mu_s * penetration;
+            const float len = sqrt_rn(dot3(tx, ty, tz, tx, ty, tz));
+            if (len > threshold) {
+                const float coeff = fminf(D.mu_k * penetration / len, 1.f);
+                tx = coeff * tx;
+                ty = coeff * ty;
+                tz = coeff * tz;
+            }
+            const float s = -(w0 / w_sum);
+            cx += s * tx;
+            cy += s * ty;
+            cz += s * tz;
+        }
+    }
+    ax += cx;
+    ay += cy;
+    az += cz;
+}
+
+template <bool FRICTION, bool UNIFORM_MASS>
+__global__ __launch_bounds__(BLOCK) void k_dem_pass(
+    const float4* __restrict__ prd, float4* __restrict__ prd_out, const float4* __restrict__ pos,
+    const uint32_t* __restrict__ cell_start, uint32_t n, GridConsts G, DemConsts D,
+    float uniform_mass, const float4* __restrict__ bprd, const float* __restrict__ bmass,
+    const uint32_t* __restrict__ b_cell_start) {
+    const uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 xi = prd[i];
+    const float4 oi = pos[i];
+    const float w0 = 1.f / (UNIFORM_MASS ? uniform_mass : oi.w);
+    const int32_t cx = floor_cell(xi.x, G.spacing), cy = floor_cell(xi.y, G.spacing),
+                  cz = floor_cell(xi.z, G.spacing);
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const uint32_t k = cell_key(G, cx + dx, cy + dy, cz + dz);
+                const uint32_t a = cell_start[k], b = cell_start[k + 1];
+                float px = 0.f, py = 0.f, pz = 0.f;
+                for (uint32_t j = a; j < b; ++j) {
+                    if (j == i) continue;
+                    const float4 xj = prd[j];
+                    const float4 oj = pos[j];
+                    const float w1 = 1.f / (UNIFORM_MASS ? uniform_mass : oj.w);
+                    dem_term<FRICTION>(D, xi, oi, xj, oj, true, w0, w1, px, py, pz);
+                }
+                sx += px;
+                sy += py;
+                sz += pz;
+            }
+    if (b_cell_start) {
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const uint32_t k = cell_key(G, cx + dx, cy + dy, cz + dz);
+                    const uint32_t a = b_cell_start[k], b = b_cell_start[k + 1];
+                    float px = 0.f, py = 0.f, pz = 0.f;
+                    for (uint32_t j = a; j < b; ++j) {
+                        const float4 xj = bprd[j];
+                        dem_term<FRICTION>(D, xi, oi, xj, xj, false, w0, 1.f / bmass[j], px, py, pz);
+                    }
+                    sx += px;
+                    sy += py;
+                    sz += pz;
+                }
+    }
+    prd_out[i] = make_float4(xi.x + sx, xi.y + sy, xi.z + sz, xi.w);
+}
+
 // a18: ParticleSet::Update (Particle.cpp:207-215): v = (new - p) / dt; p = new
 __global__ __launch_bounds__(BLOCK) void k_finalize(float4* __restrict__ pos,
                                                     float4* __restrict__ vel,
@@ -1614,7 +1722,7 @@ int set_device(pbf_ctx* c) {
     } while (0)
 
 // sort + neighbour table of the live prd (histogram must already be in cell_count)
-int sort_and_neighbors(pbf_ctx* c) {
+int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true) {
     const uint32_t n = c->n;
     GridConsts G = make_grid(c->P);
     {
@@ -1635,6 +1743,11 @@ int sort_and_neighbors(pbf_ctx* c) {
             c->prd_cur = pd;
         }
         LAUNCH_CK(c);
+    }
+    if (!with_neighbors) {
+        c->keyed = false;
+        c->grid_valid = false;   // cells are sorted, but there is no neighbour table
+        return PBF_OK;
     }
     if (n) {
         PhaseScope ps(c, PH_NEIGHBORS);
@@ -2533,6 +2646,40 @@ int pbf_step(pbf_ctx* c, float dt) {
     rc = pbf_solve(c, c->iterations, dt);
     if (rc) return rc;
     return pbf_finalize(c, dt);
+}
+
+int pbf_step_dem(pbf_ctx* c, float dt, const pbf_dem_params* dem) {
+    ENTER(c);
+    if (!dem) return fail(c, PBF_ERR_INVALID, "null dem params");
+    if (!(dem->particle_radius > 0.f) || dem->iterations < 0) return fail(c, PBF_ERR_INVALID, "bad dem params");
+    if (c->slab) return fail(c, PBF_ERR_INVALID, "the DEM solver is not available in slab mode");
+    int rc = pbf_predict(c, dt);
+    if (rc) return rc;
+    if ((rc = sort_and_neighbors(c, false))) return rc;
+    const uint32_t n = c->n;
+    if (!n) return PBF_OK;
+    const DemConsts D = {2.f * dem->particle_radius, dem->static_friction, dem->kinematic_friction};
+    const GridConsts G = make_grid(c->P);
+    {
+        PhaseScope ps(c, PH_DELTA);
+        for (int32_t it = 0; it <= dem->iterations; ++it) {
+            const bool friction = it == dem->iterations;
+            const float4* x = c->prd[c->prd_cur];
+            float4* y = c->prd[(c->prd_cur + 1) % 3];
+#define LAUNCH_DEM(F, U)                                                                          \
+    k_dem_pass<F, U><<<nblocks(n), BLOCK, 0, c->stream>>>(x, y, c->pos[c->cur], c->cell_start, n, G, D, \
+                                                          c->uniform_mass, c->bprd, c->bmass,     \
+                                                          c->nb ? c->b_cell_start : nullptr)
+            if (friction && c->uniform) LAUNCH_DEM(true, true);
+            else if (friction) LAUNCH_DEM(true, false);
+            else if (c->uniform) LAUNCH_DEM(false, true);
+            else LAUNCH_DEM(false, false);
+#undef LAUNCH_DEM
+            c->prd_cur = (c->prd_cur + 1) % 3;
+        }
+        LAUNCH_CK(c);
+    }
+    return finalize_stage(c, 0, dt);
 }
 
 int pbf_sync(pbf_ctx* c) {

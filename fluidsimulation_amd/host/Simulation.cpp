@@ -235,6 +235,19 @@ bool Simulation::Step(float dt) {
     return true;
 }
 
+bool Simulation::StepDEM(float dt) {
+    if (!m_initialized) return false;
+    if (m_pause) return true;
+    pbf_ctx* c = m_particle_system->context();
+    m_neighbor_searcher->invalidate();
+    m_dem.iterations = (int32_t)m_solver->getSolverIteration();
+    if (pbf_step_dem(c, dt, &m_dem) != PBF_OK) {
+        m_error = pbf_last_error(c);
+        return false;
+    }
+    return true;
+}
+
 float Simulation::getRestDensity() {
     float v = 0.f;
     if (m_particle_system && m_particle_system->context())

@@ -30,6 +30,10 @@ public:
     // Simulation.cpp:80-138: false if not initialised, true (and nothing done) while paused
     bool Step(float dt);
     bool StepCUDA(float dt) { return Step(dt); }  // Simulation.cpp:140-250: one path here
+    // the granular variant of StepCUDA: solve_pbd_dem in place of solve_sph_fluid (the call the
+    // reference keeps commented out at Simulation.cpp:202-213); iterations = the solver's count
+    bool StepDEM(float dt);
+    pbf_dem_params& demParams() { return m_dem; }  // SimParams' radius / friction, Simulation.cpp:335,349-350
 
     bool AddCollider(Collider* collider);          // Simulation.cpp:252-256
     void SetSolverIteration(uint32_t iter_count);  // Simulation.cpp:268-271
@@ -50,6 +54,7 @@ private:
     bool m_initialized = false;
     bool m_pause = true;
     pbf_params m_params;
+    pbf_dem_params m_dem{0.012331058f, 1.0f, 0.75f, 3};
     std::shared_ptr<ConstraintSolver> m_solver;
     std::shared_ptr<ParticleSystem> m_particle_system;
     std::shared_ptr<NeighborSearch> m_neighbor_searcher;

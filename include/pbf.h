@@ -242,6 +242,25 @@ int pbf_get_boundary_neighbors(pbf_ctx* ctx, uint32_t* fluid_counts, uint32_t* f
                                uint32_t stride_f, uint32_t* boundary_counts,
                                uint32_t* boundary_to_fluid, uint32_t stride_b);
 
+/* ---- PBD granular / DEM solver -------------------------------------
+ * Replaces solve_pbd_dem (cuda_simulation.cuh:81-90, cuda_simulation.cu:2158-2225; its only call
+ * site is commented out at Simulation.cpp:202-213): `iterations` Jacobi passes of the
+ * non-penetration correction (compute_distance_correction, :1867-1926: every particle within one
+ * diameter, fluid set then boundary set, 27 cells in z, y, x order around the particle's CURRENT
+ * cell, bucket membership frozen at the sort), one Coulomb friction pass
+ * (compute_friction_correction, :2084-2156) and the velocity update (finalize_correction,
+ * :1491-1518).  PARITY UNPINNED: CUDA-only dead code in the reference; checked against this
+ * repo's CPU restatement in plain fp32. */
+typedef struct pbf_dem_params {
+    float   particle_radius;     /* SimParams.particle_radius, Simulation.cpp:326,335 */
+    float   static_friction;     /* 1.0f,  Simulation.cpp:349 */
+    float   kinematic_friction;  /* 0.75f, Simulation.cpp:350 */
+    int32_t iterations;          /* `iterations` of StepCUDA (3, Simulation.cpp:148) */
+} pbf_dem_params;
+/* one sub-step: pbf_predict (+ colliders), counting sort (no neighbour table), the DEM solve,
+ * velocity update.  Boundary particles set with pbf_set_boundary take part. */
+int pbf_step_dem(pbf_ctx* ctx, float dt, const pbf_dem_params* dem);
+
 /* ---- slab decomposition over the GPUs of one node.  No counterpart in the
  * reference, which is single-GPU (cuda_simulation.cu has no multi-device code).  A ctx owns
  * the cells whose x index is in [x_lo, x_hi); neighbours exchange particle records of

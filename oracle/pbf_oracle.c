@@ -1130,6 +1130,128 @@ int orc_step(orc_ctx* c, float dt) {
 
 /* ---------------------------------------------------------------- getters */
 
+/* ---------------------------------------------------------------- PBD granular / DEM
+ * Build-side (PARITY UNPINNED): solve_pbd_dem of the reference's CUDA path
+ * (cuda_simulation.cu:1730-2225; dead code there, call site commented out at
+ * Simulation.cpp:202-213) restated in plain fp32 with helper_math's operator forms
+ * (length = sqrtf(dot), dot = (x*x + y*y) + z*z).  Buckets are the ones of the last
+ * SpatialSearch (membership frozen for the sub-step, like the CUDA path's sorted cells); the
+ * 27-cell sweep is centred on the particle's CURRENT cell (calcGridPos(pos), :1887) and runs z
+ * outermost, x innermost (:1891-1906), ascending index inside a cell. */
+
+typedef struct { float two_r, mu_s, mu_k; } dem_t;
+
+/* pbd_distance_correction (+_boundary), :1730-1865: one neighbour's term; w1 = its massInv */
+static inline void dem_distance_term(const dem_t* D, const float pi[3], const float pj[3], float w0,
+                                     float w1, float acc[3]) {
+    float v[3] = {pi[0] - pj[0], pi[1] - pj[1], pi[2] - pj[2]};
+    float dist = sqrtf(dot3(v, v));
+    float cj[3] = {0.f, 0.f, 0.f};
+    if (dist <= D->two_r) {
+        float w_sum = w0 + w1;
+        float C = dist - D->two_r;
+        float n[3] = {v[0] / dist, v[1] / dist, v[2] / dist};
+        float s = -w0 * (1.f / w_sum) * C;
+        cj[0] = s * n[0]; cj[1] = s * n[1]; cj[2] = s * n[2];
+    }
+    acc[0] += cj[0]; acc[1] += cj[1]; acc[2] += cj[2];
+}
+
+/* pbd_friction_correction (+_boundary), :1928-2082; d1 = neighbour's displacement this
+ * sub-step (NULL for a boundary particle) */
+static inline void dem_friction_term(const dem_t* D, const float pi[3], const float oi[3],
+                                     const float pj[3], const float* oj, float w0, float w1,
+                                     float acc[3]) {
+    float v[3] = {pi[0] - pj[0], pi[1] - pj[1], pi[2] - pj[2]};
+    float dist = sqrtf(dot3(v, v));
+    float cj[3] = {0.f, 0.f, 0.f};
+    if (dist <= D->two_r) {
+        float w_sum = w0 + w1;
+        float n[3] = {v[0] / dist, v[1] / dist, v[2] / dist};
+        float penetration = D->two_r - dist;
+        float dx[3] = {pi[0] - oi[0], pi[1] - oi[1], pi[2] - oi[2]};
+        if (oj) { /* (predict0 - original0) + (predict1 - original1), :1978 (sic: a sum) */
+            dx[0] = dx[0] + (pj[0] - oj[0]); dx[1] = dx[1] + (pj[1] - oj[1]); dx[2] = dx[2] + (pj[2] - oj[2]);
+        }
+        float dn = dot3(dx, n);
+        float t[3] = {dx[0] - dn * n[0], dx[1] - dn * n[1], dx[2] - dn * n[2]};
+        float threshold = D->mu_s * penetration;
+        float len = sqrtf(dot3(t, t));
+        if (len > threshold) {
+            float coeff = fminf(D->mu_k * penetration / len, 1.f);
+            t[0] = coeff * t[0]; t[1] = coeff * t[1]; t[2] = coeff * t[2];
+        }
+        float s = -(w0 / w_sum);
+        cj[0] += s * t[0]; cj[1] += s * t[1]; cj[2] += s * t[2];
+    }
+    acc[0] += cj[0]; acc[1] += cj[1]; acc[2] += cj[2];
+}
+
+/* one Jacobi pass: newp = pred + correction, then pred = newp (apply_correction, :1466-1488) */
+static void dem_pass(orc_ctx* c, const dem_t* D, int friction) {
+    const int n = (int)c->n;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(c->threads)
+    for (int i = 0; i < n; ++i) {
+        const float* pi = c->pred + 3 * i;
+        const float* oi = c->pos + 3 * i;
+        const float w0 = 1.f / c->mass[i];
+        int32_t g[3];
+        orc_flooring(pi, c->P.grid_spacing, g);
+        float corr[3] = {0.f, 0.f, 0.f};
+        for (int32_t z = -1; z <= 1; ++z)
+            for (int32_t y = -1; y <= 1; ++y)
+                for (int32_t x = -1; x <= 1; ++x) {
+                    const int32_t cell[3] = {g[0] + x, g[1] + y, g[2] + z};
+                    bucket_t* bk = table_find(c, orc_hash_value(cell[0], cell[1], cell[2]), 0);
+                    if (!bk) continue;
+                    float part[3] = {0.f, 0.f, 0.f}; /* the per-cell `correction` / `result` */
+                    for (int32_t pj = bk->head; pj >= 0; pj = c->next[pj]) {
+                        const int32_t* cj = c->cell + 3 * pj; /* bucket cell, frozen at the search */
+                        if (cj[0] != cell[0] || cj[1] != cell[1] || cj[2] != cell[2]) continue;
+                        if (pj == i) continue; /* adds a zero term in the reference: no effect */
+                        const float w1 = 1.f / c->mass[pj];
+                        if (friction) dem_friction_term(D, pi, oi, c->pred + 3 * pj, c->pos + 3 * pj, w0, w1, part);
+                        else dem_distance_term(D, pi, c->pred + 3 * pj, w0, w1, part);
+                    }
+                    corr[0] += part[0]; corr[1] += part[1]; corr[2] += part[2];
+                }
+        if (c->nb)
+            for (int32_t z = -1; z <= 1; ++z)
+                for (int32_t y = -1; y <= 1; ++y)
+                    for (int32_t x = -1; x <= 1; ++x) {
+                        const int32_t cell[3] = {g[0] + x, g[1] + y, g[2] + z};
+                        uint32_t lo, hi;
+                        bcell_range(c, cell, &lo, &hi);
+                        float part[3] = {0.f, 0.f, 0.f};
+                        for (uint32_t t = lo; t < hi; ++t) {
+                            const uint32_t b = c->border[t];
+                            const float w1 = 1.f / c->bmass[b];
+                            if (friction) dem_friction_term(D, pi, oi, c->bpos + 3 * (size_t)b, NULL, w0, w1, part);
+                            else dem_distance_term(D, pi, c->bpos + 3 * (size_t)b, w0, w1, part);
+                        }
+                        corr[0] += part[0]; corr[1] += part[1]; corr[2] += part[2];
+                    }
+        float* np = c->newp + 3 * i;
+        np[0] = pi[0] + corr[0]; np[1] = pi[1] + corr[1]; np[2] = pi[2] + corr[2];
+    }
+    memcpy(c->pred, c->newp, (size_t)c->n * 12);
+}
+
+int orc_step_dem(orc_ctx* c, float dt, const pbf_dem_params* dem) {
+    if (!c || !dem) return PBF_ERR_INVALID;
+    if (!c->pos && c->n) return PBF_ERR_NOT_INITIALIZED;
+    if (!(dem->particle_radius > 0.f) || dem->iterations < 0) return PBF_ERR_INVALID;
+    orc_predict_positions(c, dt);
+    orc_collision_detection(c, dt);
+    int rc = orc_spatial_search(c); /* buckets (the neighbour lists are not used here) */
+    if (rc) return rc;
+    const dem_t D = {2.f * dem->particle_radius, dem->static_friction, dem->kinematic_friction};
+    for (int32_t it = 0; it < dem->iterations; ++it) dem_pass(c, &D, 0);
+    dem_pass(c, &D, 1);
+    orc_update_velocity(c, dt); /* finalize_correction, :1491-1518 */
+    return PBF_OK;
+}
+
 int orc_download(orc_ctx* c, float* pos, float* vel, float* pred, float* newp) {
     if (!c) return PBF_ERR_INVALID;
     size_t b = (size_t)c->n * 12;

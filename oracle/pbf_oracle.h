@@ -41,6 +41,9 @@ int orc_get_boundary(orc_ctx* ctx, float* volume, float* density, float* lambda)
 int orc_get_boundary_neighbors(orc_ctx* ctx, uint32_t* fluid_counts, uint32_t* fluid_to_boundary,
                                uint32_t stride_f, uint32_t* boundary_counts,
                                uint32_t* boundary_to_fluid, uint32_t stride_b);
+/* PBD granular / DEM sub-step (cuda_simulation.cu:1730-2225 restated in plain fp32; PARITY
+ * UNPINNED) */
+int orc_step_dem(orc_ctx* ctx, float dt, const pbf_dem_params* dem);
 int orc_set_solver_iterations(orc_ctx* ctx, int32_t iterations);
 int orc_set_gravity(orc_ctx* ctx, float gx, float gy, float gz);
 

@@ -51,6 +51,7 @@ def load():
     lib.orc_set_boundary.argtypes = [vp, vp, vp, C.c_float, C.c_uint32]
     lib.orc_get_boundary.argtypes = [vp, vp, vp, vp]
     lib.orc_get_boundary_neighbors.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32]
+    lib.orc_step_dem.argtypes = [vp, C.c_float, vp]
     lib.orc_set_gravity.argtypes = [vp, C.c_float, C.c_float, C.c_float]
     for name in ("orc_predict_positions", "orc_collision_detection", "orc_compute_correction",
                  "orc_apply_solver_results", "orc_step"):
@@ -196,6 +197,9 @@ class Oracle:
         self._ck(self.lib.orc_get_boundary_neighbors(self._h, _ptr(fc), _ptr(fl), stride_f,
                                                      _ptr(bc), _ptr(bl), stride_b))
         return fc, fl, bc, bl
+
+    def step_dem(self, dt, dem):
+        self._ck(self.lib.orc_step_dem(self._h, C.c_float(dt), C.byref(dem)))
 
     def set_solver_iterations(self, it):
         self._ck(self.lib.orc_set_solver_iterations(self._h, it))

@@ -365,3 +365,47 @@ def test_boundary_removed_equals_never_set():
     for _ in range(3):
         o.step(DT); o2.step(DT)
     assert np.array_equal(o.download()[0], o2.download()[0])
+
+
+# ------------------------------------------------------------------ PBD granular / DEM (8(f) rank 3)
+
+def test_dem_two_overlapping_particles_separate_to_one_diameter():
+    """compute_distance_correction (cuda_simulation.cu:1730-1808): equal masses share the
+    penetration half and half along the line of centres"""
+    from fluidsimulation_amd import binding as B
+    from oracle import pyoracle
+    p = B.default_params()
+    p.capacity = 2
+    p.gravity[:] = [0, 0, 0]
+    p.grid_spacing = p.effective_radius = 0.05
+    r = 0.01
+    pos = np.array([[0.1, 0.1, 0.1], [0.1 + 1.2 * r, 0.1, 0.1]], np.float32)
+    o = pyoracle.Oracle(p)
+    o.upload(pos, uniform_mass=0.015)
+    o.step_dem(DT, B.dem_params(r, iterations=1))
+    q = o.download()[0]
+    assert abs(float(q[1, 0] - q[0, 0]) - 2 * r) < 1e-6
+    assert np.allclose(q[:, 1:], pos[:, 1:]) and abs(float(q[0, 0] + q[1, 0]) - float(pos[0, 0] + pos[1, 0])) < 1e-6
+    # a heavier particle moves less: w0 / (w0 + w1)
+    o.upload(pos, mass=np.array([0.015, 0.045], np.float32))
+    o.step_dem(DT, B.dem_params(r, iterations=1))
+    q = o.download()[0]
+    assert abs(float(pos[0, 0] - q[0, 0]) / float(q[1, 0] - pos[1, 0]) - 3.0) < 1e-3
+
+
+def test_dem_pile_rests_on_particle_walls():
+    from fluidsimulation_amd import binding as B, scenes
+    from oracle import pyoracle
+    p, pos, mass, cols, bpos, bm = scenes.boundary_tank(8, 8, 6, iterations=1)
+    h, r, _, _, _ = scenes.sim_params_constants()
+    o = pyoracle.Oracle(p)
+    o.upload(pos, uniform_mass=mass)
+    o.set_boundary(bpos, uniform_mass=bm)
+    dem = B.dem_params(float(r), iterations=3)
+    for _ in range(300):
+        o.step_dem(DT, dem)
+    q, v, _, _ = o.download()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    assert q[:, 1].min() > -0.5 * float(r)           # nothing fell through the floor layer
+    assert q[:, 0].min() > -2.0 * float(r) and q[:, 2].min() > -2.0 * float(r)
+    assert np.abs(v).max() < 1.0                      # the pile is not exploding

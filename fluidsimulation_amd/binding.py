@@ -38,6 +38,24 @@ class PbfCollider(C.Structure):
 PBF_COMM_ID_BYTES = 128
 
 
+PBF_CONSTRAINTS_PBD, PBF_CONSTRAINTS_XPBD = 0, 1
+
+
+class PbfDistanceConstraint(C.Structure):
+    _fields_ = [("p0", C.c_uint32), ("p1", C.c_uint32), ("rest_length", C.c_float),
+                ("stiffness", C.c_float), ("compliance", C.c_float)]
+
+
+def constraint_array(cons):
+    """cons: iterable of (p0, p1, rest_length, stiffness, compliance)"""
+    cons = list(cons)
+    arr = (PbfDistanceConstraint * max(1, len(cons)))()
+    for k, (a, b, rest, st, cm) in enumerate(cons):
+        arr[k].p0, arr[k].p1, arr[k].rest_length = int(a), int(b), float(rest)
+        arr[k].stiffness, arr[k].compliance = float(st), float(cm)
+    return arr, len(cons)
+
+
 class PbfDemParams(C.Structure):
     _fields_ = [("particle_radius", C.c_float), ("static_friction", C.c_float),
                 ("kinematic_friction", C.c_float), ("iterations", C.c_int32)]
@@ -181,6 +199,7 @@ SYMBOLS = [
     "pbf_get_boundary_neighbors",
     "pbf_comm_unique_id", "pbf_comm_create", "pbf_comm_destroy", "pbf_comm_rank", "pbf_comm_world",
     "pbf_comm_last_error", "pbf_comm_batch", "pbf_slab_halo_exchange", "pbf_step_dem",
+    "pbf_set_distance_constraints", "pbf_project_constraints", "pbf_get_constraint_lambdas",
 ]
 
 _lib = None
@@ -255,6 +274,9 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_slab_unpack_halo.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp, C.c_uint32]
     lib.pbf_slab_export.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.pbf_selftest_sqrt.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    lib.pbf_set_distance_constraints.argtypes = [vp, C.POINTER(PbfDistanceConstraint), C.c_uint32, C.c_int32]
+    lib.pbf_project_constraints.argtypes = [vp, C.c_float]
+    lib.pbf_get_constraint_lambdas.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
     lib.pbf_step_dem.argtypes = [vp, C.c_float, C.POINTER(PbfDemParams)]
     lib.pbf_comm_unique_id.argtypes = [vp]
     lib.pbf_comm_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
@@ -422,6 +444,20 @@ class PbfContext:
 
     def step(self, dt):
         self._ck(self.lib.pbf_step(self._h, C.c_float(dt)))
+
+    def set_distance_constraints(self, cons, mode=PBF_CONSTRAINTS_XPBD):
+        arr, k = constraint_array(cons)
+        self._ck(self.lib.pbf_set_distance_constraints(self._h, arr, k, mode))
+        self.ncons = k
+
+    def project_constraints(self, dt):
+        self._ck(self.lib.pbf_project_constraints(self._h, C.c_float(dt)))
+
+    def constraint_lambdas(self):
+        lam = np.zeros(max(1, getattr(self, "ncons", 0)), np.float32)
+        lv = C.c_uint32()
+        self._ck(self.lib.pbf_get_constraint_lambdas(self._h, _ptr(lam), C.byref(lv)))
+        return lam[:getattr(self, "ncons", 0)], int(lv.value)
 
     def step_dem(self, dt, dem: "PbfDemParams"):
         self._ck(self.lib.pbf_step_dem(self._h, C.c_float(dt), C.byref(dem)))

@@ -1066,6 +1066,95 @@ __global__ __launch_bounds__(BLOCK) void k_dem_pass(
     prd_out[i] = make_float4(xi.x + sx, xi.y + sy, xi.z + sz, xi.w);
 }
 
+// ------------------------------------------------------------------------------------
+// Generic constraint projection: DistanceConstraint::SolvePBDConstraint /
+// SolveXPBDConstraint (Constraints.cpp:61-120) in the list order of
+// ConstraintSolver::Solve{PBD,XPBD}Constraints (ConstraintSolver.cpp:35-72).  The host cuts the
+// list into levels of constraints that share no particle; inside a level every constraint is
+// independent, across levels the list order is kept per particle -> sequential Gauss-Seidel
+// result, bit for bit.  Constraint arrays are stored in level order (SoA).
+
+constexpr float CONSTRAINT_EPSILON = 0.000000000000001f;  // Constraints.cpp:5
+
+struct ConstraintSoA {
+    const uint32_t *p0, *p1;
+    const float *rest, *stiffness, *compliance;
+    float* lambda;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_slot_by_id(const uint32_t* __restrict__ id, uint32_t n,
+                                                      uint32_t* __restrict__ slot_by_id) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) slot_by_id[id[i]] = i;
+}
+
+template <bool XPBD>
+__device__ __forceinline__ void solve_distance_constraint(uint32_t c, const ConstraintSoA& K,
+                                                          const uint32_t* __restrict__ slot_by_id,
+                                                          const float4* __restrict__ pos, float4* prd,
+                                                          float dt) {
+    const uint32_t s0 = slot_by_id[K.p0[c]], s1 = slot_by_id[K.p1[c]];
+    float4 a = prd[s0], b = prd[s1];
+    const float w0 = 1.f / pos[s0].w, w1 = 1.f / pos[s1].w;  // m_massInv
+    const float w_sum = w0 + w1;
+    // glm::distance(p0, p1) = length(p1 - p0)
+    const float ex = b.x - a.x, ey = b.y - a.y, ez = b.z - a.z;
+    float distance = sqrt_rn(dot3(ex, ey, ez, ex, ey, ez));
+    const float C = distance - K.rest[c];
+    const float vx = a.x - b.x, vy = a.y - b.y, vz = a.z - b.z;
+    if (distance < CONSTRAINT_EPSILON) distance = CONSTRAINT_EPSILON;
+    if (!XPBD) {
+        const float nx = vx / distance, ny = vy / distance, nz = vz / distance;
+        const float s = (1.f / w_sum) * C;
+        const float cx = s * nx, cy = s * ny, cz = s * nz;
+        const float st = K.stiffness[c];
+        const float fa = st * -w0, fb = st * w1;
+        a.x += fa * cx; a.y += fa * cy; a.z += fa * cz;
+        b.x += fb * cx; b.y += fb * cy; b.z += fb * cz;
+    } else {
+        const float ct = K.compliance[c] / (dt * dt);  // Constraint::ComputeCompliance
+        const float lam = K.lambda[c];
+        const float delta_lambda = (-C - ct * lam) / (w_sum + ct);
+        const float cx = (delta_lambda * vx) / distance, cy = (delta_lambda * vy) / distance,
+                    cz = (delta_lambda * vz) / distance;
+        K.lambda[c] = lam + delta_lambda;
+        const float fb = -w1;
+        a.x += w0 * cx; a.y += w0 * cy; a.z += w0 * cz;
+        b.x += fb * cx; b.y += fb * cy; b.z += fb * cz;
+    }
+    prd[s0] = a;
+    prd[s1] = b;
+}
+
+// one (large) level, many workgroups
+template <bool XPBD>
+__global__ __launch_bounds__(BLOCK) void k_constraints_level(uint32_t first, uint32_t count,
+                                                             ConstraintSoA K,
+                                                             const uint32_t* __restrict__ slot_by_id,
+                                                             const float4* __restrict__ pos,
+                                                             float4* prd, float dt) {
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t < count) solve_distance_constraint<XPBD>(first + t, K, slot_by_id, pos, prd, dt);
+}
+
+// a run of small levels in ONE workgroup: a barrier (with its workgroup-scope fence) between
+// levels instead of a launch per level -- a rope listed end to end is one level per constraint
+template <bool XPBD>
+__global__ __launch_bounds__(BLOCK) void k_constraints_levels(const uint32_t* __restrict__ level_start,
+                                                              uint32_t first_level, uint32_t n_levels,
+                                                              ConstraintSoA K,
+                                                              const uint32_t* __restrict__ slot_by_id,
+                                                              const float4* __restrict__ pos,
+                                                              float4* prd, float dt) {
+    for (uint32_t l = first_level; l < first_level + n_levels; ++l) {
+        const uint32_t a = level_start[l], b = level_start[l + 1];
+        for (uint32_t c = a + threadIdx.x; c < b; c += BLOCK)
+            solve_distance_constraint<XPBD>(c, K, slot_by_id, pos, prd, dt);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // a18: ParticleSet::Update (Particle.cpp:207-215): v = (new - p) / dt; p = new
 __global__ __launch_bounds__(BLOCK) void k_finalize(float4* __restrict__ pos,
                                                     float4* __restrict__ vel,
@@ -1555,6 +1644,15 @@ struct pbf_ctx {
     uint32_t *bb = nullptr, *bb_count = nullptr, *bf = nullptr, *bf_count = nullptr;
     uint32_t *fb = nullptr, *fb_count = nullptr;
     bool b_static_valid = false;
+    // distance constraints (level-ordered SoA on the device; see k_constraints_*)
+    uint32_t ncons = 0, ncons_levels = 0;
+    int32_t cons_mode = 0;
+    uint32_t *cons_p0 = nullptr, *cons_p1 = nullptr, *cons_level_start = nullptr, *slot_by_id = nullptr;
+    float *cons_rest = nullptr, *cons_stiff = nullptr, *cons_compl = nullptr, *cons_lambda = nullptr;
+    std::vector<uint32_t> cons_order;                // level-ordered position -> list index
+    struct ConsBatch { uint32_t first_level, n_levels, first, count; bool one_block; };
+    std::vector<ConsBatch> cons_batches;
+    uint32_t cons_max_particle = 0;
     bool owns_stream = true;
     bool uniform = false;      // every particle has uniform_mass (no per-neighbour mass gather)
     float uniform_mass = 0.f;
@@ -1784,6 +1882,17 @@ int download3(pbf_ctx* c, const float4* src, float* host) {
     return PBF_OK;
 }
 
+void free_constraints(pbf_ctx* c) {
+    (void)hipFree(c->cons_p0); (void)hipFree(c->cons_p1); (void)hipFree(c->cons_level_start);
+    (void)hipFree(c->slot_by_id); (void)hipFree(c->cons_rest); (void)hipFree(c->cons_stiff);
+    (void)hipFree(c->cons_compl); (void)hipFree(c->cons_lambda);
+    c->cons_p0 = c->cons_p1 = c->cons_level_start = c->slot_by_id = nullptr;
+    c->cons_rest = c->cons_stiff = c->cons_compl = c->cons_lambda = nullptr;
+    c->ncons = c->ncons_levels = 0;
+    c->cons_order.clear();
+    c->cons_batches.clear();
+}
+
 void free_boundary(pbf_ctx* c) {
     (void)hipFree(c->bpos); (void)hipFree(c->bprd); (void)hipFree(c->bmass); (void)hipFree(c->bdens);
     (void)hipFree(c->b_rho_s); (void)hipFree(c->b_grad_s); (void)hipFree(c->bid);
@@ -1953,6 +2062,7 @@ int pbf_destroy(pbf_ctx* c) {
     (void)hipFree(c->blist[1]);
     (void)hipFree(c->slab_cnt);
     free_boundary(c);
+    free_constraints(c);
     if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PBF_OK;
@@ -2419,6 +2529,7 @@ int pbf_slab_set_bounds(pbf_ctx* c, int32_t x_lo, int32_t x_hi, int32_t ghost_la
     if (c->P.rest_density_mode != PBF_RHO0_FIXED)
         return fail(c, PBF_ERR_INVALID, "slab mode needs PBF_RHO0_FIXED (the first-frame mean is a serial global sum)");
     if (c->nb) return fail(c, PBF_ERR_INVALID, "boundary particles are not supported in slab mode yet");
+    if (c->ncons) return fail(c, PBF_ERR_INVALID, "constraints are not available in slab mode");
     c->slab = true;
     c->x_lo = x_lo;
     c->x_hi = x_hi;
@@ -2645,7 +2756,130 @@ int pbf_step(pbf_ctx* c, float dt) {
     }
     rc = pbf_solve(c, c->iterations, dt);
     if (rc) return rc;
+    if (c->ncons && (rc = pbf_project_constraints(c, dt))) return rc;  // Simulation.cpp:121
     return pbf_finalize(c, dt);
+}
+
+int pbf_set_distance_constraints(pbf_ctx* c, const pbf_distance_constraint* list, uint32_t count,
+                                 int32_t mode) {
+    ENTER(c);
+    if (count && !list) return fail(c, PBF_ERR_INVALID, "null constraint list");
+    if (mode != PBF_CONSTRAINTS_PBD && mode != PBF_CONSTRAINTS_XPBD) return fail(c, PBF_ERR_INVALID, "bad constraint mode");
+    if (c->slab && count) return fail(c, PBF_ERR_INVALID, "constraints are not available in slab mode (particles are addressed by global index)");
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    free_constraints(c);
+    c->cons_mode = mode;
+    if (!count) return PBF_OK;
+    // levels: a constraint runs one level after the latest earlier constraint on either particle
+    uint32_t max_p = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+        if (list[k].p0 == list[k].p1) return fail(c, PBF_ERR_INVALID, "constraint joins a particle to itself");
+        max_p = list[k].p0 > max_p ? list[k].p0 : max_p;
+        max_p = list[k].p1 > max_p ? list[k].p1 : max_p;
+    }
+    if (max_p >= c->cap) return fail(c, PBF_ERR_INVALID, "constraint particle index exceeds ctx capacity");
+    std::vector<uint32_t> last((size_t)max_p + 1, 0), level(count);
+    uint32_t n_levels = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint32_t l = (last[list[k].p0] > last[list[k].p1] ? last[list[k].p0] : last[list[k].p1]) + 1;
+        level[k] = l - 1;
+        last[list[k].p0] = last[list[k].p1] = l;
+        n_levels = l > n_levels ? l : n_levels;
+    }
+    std::vector<uint32_t> start((size_t)n_levels + 1, 0);
+    for (uint32_t k = 0; k < count; ++k) start[level[k] + 1]++;
+    for (uint32_t l = 0; l < n_levels; ++l) start[l + 1] += start[l];
+    std::vector<uint32_t> cursor(start.begin(), start.end() - 1), order(count);
+    for (uint32_t k = 0; k < count; ++k) order[cursor[level[k]]++] = k;   // stable inside a level
+    std::vector<uint32_t> p0(count), p1(count);
+    std::vector<float> rest(count), stiff(count), compl_(count);
+    for (uint32_t t = 0; t < count; ++t) {
+        const pbf_distance_constraint& q = list[order[t]];
+        p0[t] = q.p0;
+        p1[t] = q.p1;
+        rest[t] = q.rest_length;
+        stiff[t] = q.stiffness > 1.f ? 1.f : (q.stiffness < 0.f ? 0.f : q.stiffness);  // setStiffness
+        compl_[t] = q.compliance;
+    }
+    // launches: a level of more than 4 workgroups' worth gets its own grid, runs of smaller levels
+    // share one workgroup
+    const uint32_t big = 4 * BLOCK;
+    for (uint32_t l = 0; l < n_levels;) {
+        const uint32_t sz = start[l + 1] - start[l];
+        if (sz > big) {
+            c->cons_batches.push_back({l, 1, start[l], sz, false});
+            ++l;
+        } else {
+            uint32_t e = l;
+            while (e < n_levels && start[e + 1] - start[e] <= big) ++e;
+            c->cons_batches.push_back({l, e - l, start[l], start[e] - start[l], true});
+            l = e;
+        }
+    }
+#define C_CK(call)                                                                       \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            free_constraints(c);                                                         \
+            return fail(c, PBF_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        }                                                                                \
+    } while (0)
+    C_CK(dalloc(&c->cons_p0, (size_t)count));
+    C_CK(dalloc(&c->cons_p1, (size_t)count));
+    C_CK(dalloc(&c->cons_rest, (size_t)count));
+    C_CK(dalloc(&c->cons_stiff, (size_t)count));
+    C_CK(dalloc(&c->cons_compl, (size_t)count));
+    C_CK(dalloc(&c->cons_lambda, (size_t)count));
+    C_CK(dalloc(&c->cons_level_start, (size_t)n_levels + 1));
+    C_CK(dalloc(&c->slot_by_id, (size_t)c->cap));
+    C_CK(hipMemcpy(c->cons_p0, p0.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+    C_CK(hipMemcpy(c->cons_p1, p1.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+    C_CK(hipMemcpy(c->cons_rest, rest.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+    C_CK(hipMemcpy(c->cons_stiff, stiff.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+    C_CK(hipMemcpy(c->cons_compl, compl_.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+    C_CK(hipMemcpy(c->cons_level_start, start.data(), ((size_t)n_levels + 1) * 4, hipMemcpyHostToDevice));
+    C_CK(hipMemset(c->cons_lambda, 0, (size_t)count * 4));
+#undef C_CK
+    c->cons_order = order;
+    c->ncons = count;
+    c->ncons_levels = n_levels;
+    c->cons_max_particle = max_p;
+    return PBF_OK;
+}
+
+int pbf_project_constraints(pbf_ctx* c, float dt) {
+    ENTER(c);
+    if (!c->ncons || !c->n) return PBF_OK;
+    if (c->cons_max_particle >= c->n) return fail(c, PBF_ERR_INVALID, "constraint particle index exceeds the particle count");
+    const bool xpbd = c->cons_mode == PBF_CONSTRAINTS_XPBD;
+    const ConstraintSoA K = {c->cons_p0, c->cons_p1, c->cons_rest, c->cons_stiff, c->cons_compl, c->cons_lambda};
+    k_slot_by_id<<<nblocks(c->n), BLOCK, 0, c->stream>>>(c->id[c->cur], c->n, c->slot_by_id);
+    if (xpbd) HIP_CK(c, hipMemsetAsync(c->cons_lambda, 0, (size_t)c->ncons * 4, c->stream));  // InitLambda
+    float4* prd = c->prd[c->prd_cur];
+    const float4* pos = c->pos[c->cur];
+    for (int32_t it = 0; it < c->iterations; ++it)
+        for (const auto& b : c->cons_batches) {
+            if (b.one_block) {
+                if (xpbd) k_constraints_levels<true><<<1, BLOCK, 0, c->stream>>>(c->cons_level_start, b.first_level, b.n_levels, K, c->slot_by_id, pos, prd, dt);
+                else k_constraints_levels<false><<<1, BLOCK, 0, c->stream>>>(c->cons_level_start, b.first_level, b.n_levels, K, c->slot_by_id, pos, prd, dt);
+            } else {
+                if (xpbd) k_constraints_level<true><<<nblocks(b.count), BLOCK, 0, c->stream>>>(b.first, b.count, K, c->slot_by_id, pos, prd, dt);
+                else k_constraints_level<false><<<nblocks(b.count), BLOCK, 0, c->stream>>>(b.first, b.count, K, c->slot_by_id, pos, prd, dt);
+            }
+        }
+    LAUNCH_CK(c);
+    return PBF_OK;
+}
+
+int pbf_get_constraint_lambdas(pbf_ctx* c, float* lambdas, uint32_t* levels) {
+    ENTER(c);
+    if (levels) *levels = c->ncons_levels;
+    if (!lambdas || !c->ncons) return PBF_OK;
+    std::vector<float> tmp(c->ncons);
+    HIP_CK(c, hipMemcpyAsync(tmp.data(), c->cons_lambda, (size_t)c->ncons * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t t = 0; t < c->ncons; ++t) lambdas[c->cons_order[t]] = tmp[t];
+    return PBF_OK;
 }
 
 int pbf_step_dem(pbf_ctx* c, float dt, const pbf_dem_params* dem) {

@@ -1,7 +1,9 @@
 // ConstraintSolver.h -- mirrors the reference's ConstraintSolver (reference
 // ConstraintSolver.h:8-53).  For fluids the reference uses it only as the holder of the
-// solver iteration count (Simulation.cpp:112); its static/collision constraint lists are
-// empty in the shipped scene, so SolveConstraints is the same no-op here.
+// solver iteration count (Simulation.cpp:112) and PBD / XPBD mode.  The Gauss-Seidel sweep over
+// the static constraint list (ConstraintSolver.cpp:35-72) runs on the device inside pbf_step
+// (pbf_project_constraints) with this object's mode and iteration count, so SolveConstraints on
+// the host has nothing left to do.
 #pragma once
 #include <cstdint>
 

@@ -160,6 +160,7 @@ bool Simulation::Initialize(PBD_MODE mode, std::shared_ptr<ParticleSystem> parti
     }
     m_neighbor_searcher->Initialize();
     if (!push_colliders()) return false;
+    if (!push_constraints()) return false;
     m_initialized = true;
     return true;
 }
@@ -189,6 +190,39 @@ bool Simulation::push_colliders() {
         return false;
     }
     return true;
+}
+
+bool Simulation::push_constraints() {
+    pbf_ctx* c = m_particle_system ? m_particle_system->context() : nullptr;
+    if (!c) return true;  // pushed at Initialize
+    std::vector<pbf_distance_constraint> list;
+    for (Constraint* k : m_static_constraints)
+        list.push_back(static_cast<DistanceConstraint*>(k)->pod());
+    const int mode = (m_solver && m_solver->getPBDMode() == PBD_MODE::PBD) ? PBF_CONSTRAINTS_PBD : PBF_CONSTRAINTS_XPBD;
+    if (pbf_set_distance_constraints(c, list.data(), (uint32_t)list.size(), mode) != PBF_OK) {
+        m_error = pbf_last_error(c);
+        return false;
+    }
+    return true;
+}
+
+bool Simulation::AddStaticConstraint(Constraint* constraint) {
+    if (!constraint || constraint->getConstraintType() != CONSTRAINT_TYPE::CONSTRAINT_DISTANCE) {
+        m_error = "only DistanceConstraint is implemented (BendConstraint is a stub in the reference)";
+        return false;
+    }
+    m_static_constraints.push_back(constraint);
+    return push_constraints();
+}
+
+bool Simulation::AddStaticConstraints(const std::vector<Constraint*>& constraints) {
+    for (Constraint* k : constraints)
+        if (!k || k->getConstraintType() != CONSTRAINT_TYPE::CONSTRAINT_DISTANCE) {
+            m_error = "only DistanceConstraint is implemented (BendConstraint is a stub in the reference)";
+            return false;
+        }
+    m_static_constraints.insert(m_static_constraints.end(), constraints.begin(), constraints.end());
+    return push_constraints();
 }
 
 bool Simulation::AddCollider(Collider* collider) {

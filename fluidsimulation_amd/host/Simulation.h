@@ -7,6 +7,7 @@
 #include <vector>
 #include "Collider.h"
 #include "ConstraintSolver.h"
+#include "Constraints.h"
 #include "NeighborSearch.h"
 #include "ParticleSystem.h"
 #include "pbf.h"
@@ -36,6 +37,11 @@ public:
     pbf_dem_params& demParams() { return m_dem; }  // SimParams' radius / friction, Simulation.cpp:335,349-350
 
     bool AddCollider(Collider* collider);          // Simulation.cpp:252-256
+    // Simulation.cpp:258-266; only DistanceConstraint has an implementation in the reference
+    // (BendConstraint is an empty stub, Constraints.cpp:36-44).  Projected every Step in list
+    // order with the solver's PBD / XPBD mode and iteration count.
+    bool AddStaticConstraint(Constraint* constraint);
+    bool AddStaticConstraints(const std::vector<Constraint*>& constraints);
     void SetSolverIteration(uint32_t iter_count);  // Simulation.cpp:268-271
     void Pause() { m_pause = !m_pause; }           // Simulation.cpp:302-305
     void setGravity(float gravity);                // Simulation.cpp:307-310
@@ -50,6 +56,8 @@ public:
 
 private:
     bool push_colliders();
+    bool push_constraints();
+    std::vector<Constraint*> m_static_constraints;
     SimWorldDesc m_world_desc;
     bool m_initialized = false;
     bool m_pause = true;

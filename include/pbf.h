@@ -261,6 +261,32 @@ typedef struct pbf_dem_params {
  * velocity update.  Boundary particles set with pbf_set_boundary take part. */
 int pbf_step_dem(pbf_ctx* ctx, float dt, const pbf_dem_params* dem);
 
+/* ---- generic constraint projection ---------------------------------
+ * DistanceConstraint::SolvePBDConstraint / SolveXPBDConstraint (Constraints.cpp:61-120) under
+ * ConstraintSolver::SolvePBDConstraints / SolveXPBDConstraints (ConstraintSolver.cpp:35-72):
+ * `solver_iterations` Gauss-Seidel sweeps over the list IN LIST ORDER on the new positions,
+ * between the density iterations and the velocity update (Simulation::ProjectConstraints,
+ * Simulation.cpp:121,775-780).  On the device the list is cut into levels of constraints that
+ * share no particle (a constraint's level = 1 + the highest level of an earlier constraint on
+ * either of its particles), executed level by level: every particle sees its constraints in list
+ * order, so the result is the sequential Gauss-Seidel result bit for bit.  Particles are
+ * addressed by ORIGINAL index; stiffness is clamped to [0, 1] (Constraint::setStiffness). */
+enum { PBF_CONSTRAINTS_PBD = 0, PBF_CONSTRAINTS_XPBD = 1 };  /* PBD_MODE, ConstraintSolver.h */
+typedef struct pbf_distance_constraint {
+    uint32_t p0, p1;      /* m_particles[0], m_particles[1] */
+    float    rest_length; /* m_rest_length */
+    float    stiffness;   /* m_stiffness  (PBD)  */
+    float    compliance;  /* m_compliance (XPBD) */
+} pbf_distance_constraint;
+/* Simulation::AddStaticConstraints (Simulation.cpp:258-266): replaces the list; count = 0 clears */
+int pbf_set_distance_constraints(pbf_ctx* ctx, const pbf_distance_constraint* list, uint32_t count,
+                                 int32_t mode);
+/* Simulation::ProjectConstraints: part of pbf_step when a list is set; callable on its own
+ * between pbf_solve and pbf_finalize */
+int pbf_project_constraints(pbf_ctx* ctx, float dt);
+/* XPBD multipliers m_lambda after the last projection, list order; levels = device schedule depth */
+int pbf_get_constraint_lambdas(pbf_ctx* ctx, float* lambdas, uint32_t* levels);
+
 /* ---- slab decomposition over the GPUs of one node.  No counterpart in the
  * reference, which is single-GPU (cuda_simulation.cu has no multi-device code).  A ctx owns
  * the cells whose x index is in [x_lo, x_hi); neighbours exchange particle records of

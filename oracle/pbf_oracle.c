@@ -56,6 +56,10 @@ struct orc_ctx {
     uint64_t *bb_off, *fb_off, *bf_off; /* boundary-boundary (static), fluid->boundary, boundary->fluid */
     uint32_t *bb, *fb, *bf;
     uint64_t fb_cap, bf_cap;
+    pbf_distance_constraint* cons; /* m_static_constraints, Simulation.h */
+    float* cons_lambda;
+    uint32_t ncons;
+    int32_t cons_mode;
     int first_frame;      /* m_first_frame, Simulation.cpp:17 */
     float rest_density;   /* m_rest_density */
     int32_t iterations;   /* ConstraintSolver::m_solver_iteration */
@@ -312,6 +316,7 @@ int orc_destroy(orc_ctx* c) {
     if (!c) return PBF_ERR_INVALID;
     free_particles(c);
     free_boundary(c);
+    free(c->cons); free(c->cons_lambda);
     free(c);
     return PBF_OK;
 }
@@ -1123,7 +1128,7 @@ int orc_step(orc_ctx* c, float dt) {
         orc_compute_correction(c, dt);
         orc_update_predict_position(c);
     }
-    /* ProjectConstraints over empty lists is a no-op, ConstraintSolver.cpp:12-72 */
+    orc_project_constraints(c, dt); /* Simulation.cpp:121; no-op over an empty list */
     orc_apply_solver_results(c, dt);
     return PBF_OK;
 }
@@ -1249,6 +1254,78 @@ int orc_step_dem(orc_ctx* c, float dt, const pbf_dem_params* dem) {
     for (int32_t it = 0; it < dem->iterations; ++it) dem_pass(c, &D, 0);
     dem_pass(c, &D, 1);
     orc_update_velocity(c, dt); /* finalize_correction, :1491-1518 */
+    return PBF_OK;
+}
+
+/* ---------------------------------------------------------------- generic constraints
+ * Simulation::ProjectConstraints -> ConstraintSolver::SolveConstraints (Simulation.cpp:775-780,
+ * ConstraintSolver.cpp:12-72) over DistanceConstraint (Constraints.cpp:61-120), operating on
+ * m_new_positions.  (The reference's Constraint holds legacy Particle objects; here the two
+ * particles are indices into the ParticleSet.)  Constraints.cpp cannot be compiled in this
+ * image (Particle.h pulls in cuda_runtime.h), so this is pinned by the source text only. */
+#define CONSTRAINT_EPSILON 0.000000000000001f /* Constraints.cpp:5 */
+
+int orc_set_distance_constraints(orc_ctx* c, const pbf_distance_constraint* list, uint32_t count, int32_t mode) {
+    if (!c || (count && !list)) return PBF_ERR_INVALID;
+    if (mode != PBF_CONSTRAINTS_PBD && mode != PBF_CONSTRAINTS_XPBD) return PBF_ERR_INVALID;
+    free(c->cons); free(c->cons_lambda);
+    c->cons = NULL; c->cons_lambda = NULL; c->ncons = 0; c->cons_mode = mode;
+    if (!count) return PBF_OK;
+    c->cons = (pbf_distance_constraint*)xcalloc(count, sizeof(*list));
+    c->cons_lambda = (float*)xcalloc(count, 4);
+    memcpy(c->cons, list, (size_t)count * sizeof(*list));
+    for (uint32_t k = 0; k < count; ++k) { /* Constraint::setStiffness, Constraints.cpp:25-33 */
+        float s = c->cons[k].stiffness;
+        c->cons[k].stiffness = s > 1.f ? 1.f : (s < 0.f ? 0.f : s);
+    }
+    c->ncons = count;
+    return PBF_OK;
+}
+
+int orc_project_constraints(orc_ctx* c, float dt) {
+    if (!c) return PBF_ERR_INVALID;
+    if (!c->ncons) return PBF_OK;
+    for (uint32_t k = 0; k < c->ncons; ++k)
+        if (c->cons[k].p0 >= c->n || c->cons[k].p1 >= c->n) return PBF_ERR_INVALID;
+    const int xpbd = c->cons_mode == PBF_CONSTRAINTS_XPBD;
+    if (xpbd) /* InitLambda + ComputeCompliance, ConstraintSolver.cpp:55-60 */
+        for (uint32_t k = 0; k < c->ncons; ++k) c->cons_lambda[k] = 0.0f;
+    for (int32_t it = 0; it < c->iterations; ++it)
+        for (uint32_t k = 0; k < c->ncons; ++k) {
+            const pbf_distance_constraint* q = &c->cons[k];
+            float* p0 = c->newp + 3 * (size_t)q->p0;
+            float* p1 = c->newp + 3 * (size_t)q->p1;
+            const float w0 = 1.f / c->mass[q->p0], w1 = 1.f / c->mass[q->p1];
+            float w_sum = w0 + w1;
+            float distance = dist3(p0, p1);
+            float C = distance - q->rest_length;
+            float v[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
+            if (distance < CONSTRAINT_EPSILON) distance = CONSTRAINT_EPSILON;
+            if (!xpbd) { /* SolvePBDConstraint, Constraints.cpp:61-89 */
+                float n[3] = {v[0] / distance, v[1] / distance, v[2] / distance};
+                float s = (1.f / w_sum) * C;
+                float corr[3] = {s * n[0], s * n[1], s * n[2]};
+                float a = q->stiffness * -w0, b = q->stiffness * w1;
+                p0[0] += a * corr[0]; p0[1] += a * corr[1]; p0[2] += a * corr[2];
+                p1[0] += b * corr[0]; p1[1] += b * corr[1]; p1[2] += b * corr[2];
+            } else { /* SolveXPBDConstraint, Constraints.cpp:91-120 */
+                const float ct = q->compliance / (dt * dt);
+                float delta_lambda = (-C - ct * c->cons_lambda[k]) / (w_sum + ct);
+                float corr[3] = {(delta_lambda * v[0]) / distance, (delta_lambda * v[1]) / distance,
+                                 (delta_lambda * v[2]) / distance};
+                c->cons_lambda[k] += delta_lambda;
+                float b = -w1;
+                p0[0] += w0 * corr[0]; p0[1] += w0 * corr[1]; p0[2] += w0 * corr[2];
+                p1[0] += b * corr[0]; p1[1] += b * corr[1]; p1[2] += b * corr[2];
+            }
+        }
+    memcpy(c->pred, c->newp, (size_t)c->n * 12); /* the device path keeps ONE predicted/new array */
+    return PBF_OK;
+}
+
+int orc_get_constraint_lambdas(orc_ctx* c, float* lambdas) {
+    if (!c || !lambdas) return PBF_ERR_INVALID;
+    if (c->ncons) memcpy(lambdas, c->cons_lambda, (size_t)c->ncons * 4);
     return PBF_OK;
 }
 

@@ -44,6 +44,11 @@ int orc_get_boundary_neighbors(orc_ctx* ctx, uint32_t* fluid_counts, uint32_t* f
 /* PBD granular / DEM sub-step (cuda_simulation.cu:1730-2225 restated in plain fp32; PARITY
  * UNPINNED) */
 int orc_step_dem(orc_ctx* ctx, float dt, const pbf_dem_params* dem);
+/* DistanceConstraint list under ConstraintSolver::SolveConstraints (Constraints.cpp:61-120,
+ * ConstraintSolver.cpp:12-72), sequential Gauss-Seidel in list order */
+int orc_set_distance_constraints(orc_ctx* ctx, const pbf_distance_constraint* list, uint32_t count, int32_t mode);
+int orc_project_constraints(orc_ctx* ctx, float dt);
+int orc_get_constraint_lambdas(orc_ctx* ctx, float* lambdas);
 int orc_set_solver_iterations(orc_ctx* ctx, int32_t iterations);
 int orc_set_gravity(orc_ctx* ctx, float gx, float gy, float gz);
 

@@ -409,3 +409,65 @@ def test_dem_pile_rests_on_particle_walls():
     assert q[:, 1].min() > -0.5 * float(r)           # nothing fell through the floor layer
     assert q[:, 0].min() > -2.0 * float(r) and q[:, 2].min() > -2.0 * float(r)
     assert np.abs(v).max() < 1.0                      # the pile is not exploding
+
+
+# ------------------------------------------------------------------ distance constraints (8(f) rank 4)
+
+def _two_particles(mode, stiffness=1.0, compliance=0.0, iters=1, masses=None):
+    from fluidsimulation_amd import binding as B
+    from oracle import pyoracle
+    p = B.default_params()
+    p.capacity = 2
+    p.gravity[:] = [0, 0, 0]
+    p.solver_iterations = iters
+    pos = np.array([[0.0, 0.0, 0.0], [3.0, 4.0, 0.0]], np.float32)   # 5 apart, more than h: no fluid coupling
+    o = pyoracle.Oracle(p)
+    o.upload(pos, mass=masses, uniform_mass=2.0)
+    o.set_distance_constraints([(0, 1, 2.0, stiffness, compliance)], mode)
+    o.step(DT)
+    return pos, o.download()[0], o
+
+
+def test_distance_constraint_pbd_and_xpbd_by_hand():
+    """Constraints.cpp:61-120: stiffness 1 (PBD) and compliance 0 (XPBD) restore the rest length in
+    one projection; the correction splits by inverse mass"""
+    from fluidsimulation_amd import binding as B
+    for mode in (B.PBF_CONSTRAINTS_PBD, B.PBF_CONSTRAINTS_XPBD):
+        pos, q, o = _two_particles(mode)
+        assert abs(np.linalg.norm(q[1] - q[0]) - 2.0) < 1e-5
+        assert np.allclose(q[0] + q[1], pos[0] + pos[1], atol=1e-5)          # equal masses: symmetric
+    # PBD stiffness 0.5: half the error is removed
+    _, q, _ = _two_particles(B.PBF_CONSTRAINTS_PBD, stiffness=0.5)
+    assert abs(np.linalg.norm(q[1] - q[0]) - 3.5) < 1e-5
+    # stiffness is clamped to [0, 1] (Constraint::setStiffness)
+    _, q, _ = _two_particles(B.PBF_CONSTRAINTS_PBD, stiffness=7.0)
+    assert abs(np.linalg.norm(q[1] - q[0]) - 2.0) < 1e-5
+    # XPBD: lambda = -C / (w_sum + alpha/dt^2); softer with compliance
+    _, q, o = _two_particles(B.PBF_CONSTRAINTS_XPBD, compliance=1e-6)
+    ct = np.float32(1e-6) / (np.float32(DT) * np.float32(DT))
+    lam = o.constraint_lambdas()[0]
+    assert lam == pytest.approx(-(5.0 - 2.0) / (1.0 + float(ct)), rel=1e-5)
+    # heavier particle moves less
+    pos, q, _ = _two_particles(B.PBF_CONSTRAINTS_PBD, masses=np.array([1.0, 3.0], np.float32))
+    assert np.linalg.norm(q[0] - pos[0]) / np.linalg.norm(q[1] - pos[1]) == pytest.approx(3.0, rel=1e-4)
+
+
+def test_constraint_list_is_gauss_seidel_in_list_order():
+    """a 3-particle chain: the second constraint sees the first one's correction; reversing the
+    list changes the result (ConstraintSolver.cpp:41-48 sweeps the list in order)"""
+    from fluidsimulation_amd import binding as B
+    from oracle import pyoracle
+    p = B.default_params()
+    p.capacity = 3
+    p.gravity[:] = [0, 0, 0]
+    pos = np.array([[0, 0, 0], [3, 0, 0], [6, 1, 0]], np.float32)
+    out = []
+    for cons in ([(0, 1, 2.0, 1, 0), (1, 2, 2.0, 1, 0)], [(1, 2, 2.0, 1, 0), (0, 1, 2.0, 1, 0)]):
+        o = pyoracle.Oracle(p)
+        o.upload(pos, uniform_mass=1.0)
+        o.set_distance_constraints(cons, B.PBF_CONSTRAINTS_PBD)
+        o.step(DT)
+        out.append(o.download()[0])
+    assert not np.allclose(out[0], out[1])
+    assert abs(np.linalg.norm(out[0][2] - out[0][1]) - 2.0) < 1e-5   # the LAST constraint is satisfied
+    assert abs(np.linalg.norm(out[1][1] - out[1][0]) - 2.0) < 1e-5

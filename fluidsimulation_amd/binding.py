@@ -200,6 +200,7 @@ SYMBOLS = [
     "pbf_comm_unique_id", "pbf_comm_create", "pbf_comm_destroy", "pbf_comm_rank", "pbf_comm_world",
     "pbf_comm_last_error", "pbf_comm_batch", "pbf_slab_halo_exchange", "pbf_step_dem",
     "pbf_set_distance_constraints", "pbf_project_constraints", "pbf_get_constraint_lambdas",
+    "pbf_comm_local_id", "pbf_slab_attach", "pbf_slab_step", "pbf_slab_owned_count",
 ]
 
 _lib = None
@@ -279,6 +280,11 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_get_constraint_lambdas.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
     lib.pbf_step_dem.argtypes = [vp, C.c_float, C.POINTER(PbfDemParams)]
     lib.pbf_comm_unique_id.argtypes = [vp]
+    lib.pbf_comm_local_id.argtypes = [vp]
+    lib.pbf_slab_attach.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32]
+    lib.pbf_slab_step.argtypes = [vp, C.c_float]
+    lib.pbf_slab_owned_count.argtypes = [vp]
+    lib.pbf_slab_owned_count.restype = C.c_uint32
     lib.pbf_comm_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.pbf_comm_destroy.argtypes = [vp]
     lib.pbf_comm_rank.argtypes = [vp]
@@ -316,6 +322,14 @@ class RcclComm:
         if rc != PBF_OK:
             raise PbfError(rc, (self.lib.pbf_comm_last_error(None) or b"pbf_comm_create failed").decode())
         self.rank, self.world = rank, world
+
+    @staticmethod
+    def local_id() -> bytes:
+        """id of the in-process loopback transport (ranks = threads of this process; tests)"""
+        lib = load_library()
+        buf = C.create_string_buffer(PBF_COMM_ID_BYTES)
+        lib.pbf_comm_local_id(buf)
+        return buf.raw
 
     @staticmethod
     def unique_id() -> bytes:
@@ -572,6 +586,17 @@ class PbfContext:
         self._ck(self.lib.pbf_slab_halo_exchange(self._h, comm._h, what, left, right,
                                                  C.c_void_p(d_send_left or None), C.c_void_p(d_send_right or None),
                                                  C.c_void_p(d_recv_left or None), C.c_void_p(d_recv_right or None)))
+
+    def slab_attach(self, comm: "RcclComm", left: int, right: int, max_records: int = 0):
+        self._ck(self.lib.pbf_slab_attach(self._h, comm._h, left, right, max_records))
+        self._comm = comm   # keep the communicator alive as long as the ctx uses it
+
+    def slab_step(self, dt):
+        self._ck(self.lib.pbf_slab_step(self._h, C.c_float(dt)))
+        self.n = int(self.lib.pbf_num_particles(self._h))
+
+    def slab_owned_count(self) -> int:
+        return int(self.lib.pbf_slab_owned_count(self._h))
 
     def slab_export(self, d_records: int, max_records: int) -> int:
         k = C.c_uint32()

@@ -15,9 +15,15 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "pbf.h"
 
@@ -89,10 +95,35 @@ const Rccl* rccl() {
     return &g_rccl;
 }
 
+// ---- in-process loopback transport (tests): the ranks are threads of ONE process, each with
+// its own ctx and stream, possibly all on one GPU.  Same contract as the RCCL path -- the k-th
+// send from a to b pairs with b's k-th receive from a; a send buffer may be reused once the
+// stream has passed the batch -- implemented with a mailbox per ordered rank pair, events and
+// device-to-device copies.  A communicator id that starts with "PBFLOCAL" selects it.
+struct LocalMsg {
+    const void* buf = nullptr;
+    uint64_t bytes = 0;
+    hipEvent_t ready = nullptr;   // recorded on the sender's stream before the message is posted
+    hipEvent_t done = nullptr;    // recorded on the receiver's stream after its copy
+    bool consumed = false, failed = false;
+};
+
+struct LocalGroup {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::map<std::pair<int, int>, std::deque<std::shared_ptr<LocalMsg>>> box;  // (from, to)
+    int joined = 0;
+};
+
+std::mutex g_local_mu;
+std::map<std::string, std::shared_ptr<LocalGroup>> g_local_groups;
+
 }  // namespace
 
 struct pbf_comm {
     NcclComm comm = nullptr;
+    std::shared_ptr<LocalGroup> local;   // set for the loopback transport
     int rank = 0, world = 1, device = 0;
     std::string err = "no error";
 };
@@ -103,6 +134,79 @@ int comm_fail(pbf_comm* c, int code, const std::string& msg) {
     else g_comm_err = msg;
     return code;
 }
+bool is_local_id(const void* id) { return memcmp(id, "PBFLOCAL", 8) == 0; }
+
+int local_batch(pbf_comm* c, hipStream_t s, const pbf_p2p* ops, uint32_t n_ops) {
+    LocalGroup& G = *c->local;
+    std::vector<std::shared_ptr<LocalMsg>> mine;
+    // 1. post every send (never blocks)
+    for (uint32_t i = 0; i < n_ops; ++i) {
+        const pbf_p2p& op = ops[i];
+        if (!op.bytes || !op.send) continue;
+        auto m = std::make_shared<LocalMsg>();
+        m->buf = op.buf;
+        m->bytes = op.bytes;
+        if (hipEventCreateWithFlags(&m->ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&m->done, hipEventDisableTiming) != hipSuccess ||
+            hipEventRecord(m->ready, s) != hipSuccess)
+            return comm_fail(c, PBF_ERR_HIP, "loopback: event setup failed");
+        {
+            std::lock_guard<std::mutex> lk(G.mu);
+            G.box[{c->rank, op.peer}].push_back(m);
+        }
+        G.cv.notify_all();
+        mine.push_back(m);
+    }
+    // 2. every receive: wait for the matching message, copy behind the sender's event
+    int rc = PBF_OK;
+    for (uint32_t i = 0; i < n_ops; ++i) {
+        const pbf_p2p& op = ops[i];
+        if (!op.bytes || op.send) continue;
+        std::shared_ptr<LocalMsg> m;
+        {
+            std::unique_lock<std::mutex> lk(G.mu);
+            auto& q = G.box[{op.peer, c->rank}];
+            if (!G.cv.wait_for(lk, std::chrono::seconds(60), [&] { return !q.empty(); })) {
+                rc = comm_fail(c, PBF_ERR_INVALID, "loopback: no matching send within 60 s");
+                break;
+            }
+            m = q.front();
+            q.pop_front();
+        }
+        bool ok = m->bytes == op.bytes;
+        if (!ok) rc = comm_fail(c, PBF_ERR_INVALID, "loopback: message sizes disagree between the two ends");
+        ok = ok && hipStreamWaitEvent(s, m->ready, 0) == hipSuccess &&
+             hipMemcpyAsync(op.buf, m->buf, op.bytes, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+             hipEventRecord(m->done, s) == hipSuccess;
+        if (!ok && rc == PBF_OK) rc = comm_fail(c, PBF_ERR_HIP, "loopback: copy failed");
+        {
+            std::lock_guard<std::mutex> lk(G.mu);
+            m->consumed = true;
+            m->failed = !ok;
+        }
+        G.cv.notify_all();
+    }
+    // 3. my sends: the stream must not run past the batch before the receivers have copied
+    for (auto& m : mine) {
+        std::unique_lock<std::mutex> lk(G.mu);
+        if (!G.cv.wait_for(lk, std::chrono::seconds(60), [&] { return m->consumed; })) {
+            if (rc == PBF_OK) rc = comm_fail(c, PBF_ERR_INVALID, "loopback: a send was not received within 60 s");
+            continue;   // the events leak; the run is lost anyway
+        }
+        lk.unlock();
+        if (!m->failed && hipStreamWaitEvent(s, m->done, 0) != hipSuccess && rc == PBF_OK)
+            rc = comm_fail(c, PBF_ERR_HIP, "loopback: hipStreamWaitEvent failed");
+    }
+    // events are destroyed lazily by the runtime once their work has completed
+    for (auto& m : mine) {
+        if (m->consumed) {
+            (void)hipEventDestroy(m->ready);
+            (void)hipEventDestroy(m->done);
+        }
+    }
+    return rc;
+}
+
 std::string nccl_msg(const char* what, NcclResult r) {
     const Rccl* R = rccl();
     return std::string(what) + ": " + (R->GetErrorString ? R->GetErrorString(r) : "RCCL error") +
@@ -125,12 +229,25 @@ int pbf_comm_unique_id(void* id_out) {
     return PBF_OK;
 }
 
+int pbf_comm_local_id(void* id_out) {
+    if (!id_out) return comm_fail(nullptr, PBF_ERR_INVALID, "null id");
+    static std::mutex mu;
+    static uint64_t counter = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    memset(id_out, 0, PBF_COMM_ID_BYTES);
+    memcpy(id_out, "PBFLOCAL", 8);
+    const uint64_t v = ++counter;
+    memcpy((char*)id_out + 8, &v, sizeof(v));
+    return PBF_OK;
+}
+
 int pbf_comm_create(const void* id_in, int32_t rank, int32_t world, int32_t device, pbf_comm** out) {
     if (out) *out = nullptr;
     if (!id_in || !out || world < 1 || rank < 0 || rank >= world)
         return comm_fail(nullptr, PBF_ERR_INVALID, "bad argument");
-    const Rccl* R = rccl();
-    if (!R->ok) return comm_fail(nullptr, PBF_ERR_NO_DEVICE, R->error);
+    const bool local = is_local_id(id_in);
+    const Rccl* R = local ? nullptr : rccl();
+    if (!local && !R->ok) return comm_fail(nullptr, PBF_ERR_NO_DEVICE, R->error);
     if (device >= 0) {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return comm_fail(nullptr, PBF_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
@@ -142,6 +259,23 @@ int pbf_comm_create(const void* id_in, int32_t rank, int32_t world, int32_t devi
     c->rank = rank;
     c->world = world;
     c->device = device;
+    if (local) {
+        const std::string key((const char*)id_in, PBF_COMM_ID_BYTES);
+        std::lock_guard<std::mutex> lk(g_local_mu);
+        auto& g = g_local_groups[key];
+        if (!g) {
+            g = std::make_shared<LocalGroup>();
+            g->world = world;
+        }
+        if (g->world != world) {
+            delete c;
+            return comm_fail(nullptr, PBF_ERR_INVALID, "loopback: ranks disagree on the world size");
+        }
+        c->local = g;
+        if (++g->joined == world) g_local_groups.erase(key);   // everybody holds a reference now
+        *out = c;
+        return PBF_OK;
+    }
     NcclUniqueId id;
     memcpy(&id, id_in, sizeof(id));
     NcclResult r = R->CommInitRank(&c->comm, world, id, rank);
@@ -155,8 +289,10 @@ int pbf_comm_create(const void* id_in, int32_t rank, int32_t world, int32_t devi
 
 int pbf_comm_destroy(pbf_comm* c) {
     if (!c) return PBF_ERR_INVALID;
-    const Rccl* R = rccl();
-    if (c->comm && R->ok) (void)R->CommDestroy(c->comm);
+    if (c->comm) {
+        const Rccl* R = rccl();
+        if (R->ok) (void)R->CommDestroy(c->comm);
+    }
     delete c;
     return PBF_OK;
 }
@@ -167,8 +303,8 @@ int32_t pbf_comm_world(const pbf_comm* c) { return c ? c->world : 0; }
 int pbf_comm_batch(pbf_comm* c, void* hip_stream, const pbf_p2p* ops, uint32_t n_ops) {
     if (!c) return PBF_ERR_INVALID;
     if (n_ops && !ops) return comm_fail(c, PBF_ERR_INVALID, "null ops");
-    const Rccl* R = rccl();
-    if (!R->ok) return comm_fail(c, PBF_ERR_NO_DEVICE, R->error);
+    const Rccl* R = c->local ? nullptr : rccl();
+    if (R && !R->ok) return comm_fail(c, PBF_ERR_NO_DEVICE, R->error);
     uint32_t live = 0;
     for (uint32_t i = 0; i < n_ops; ++i) {
         if (!ops[i].bytes) continue;   // both ends skip an empty message (sizes are agreed beforehand)
@@ -180,6 +316,7 @@ int pbf_comm_batch(pbf_comm* c, void* hip_stream, const pbf_p2p* ops, uint32_t n
     hipError_t he = hipSetDevice(c->device);
     if (he != hipSuccess) return comm_fail(c, PBF_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he));
     hipStream_t s = (hipStream_t)hip_stream;
+    if (c->local) return local_batch(c, s, ops, n_ops);
     NcclResult r = R->GroupStart();
     if (r) return comm_fail(c, PBF_ERR_HIP, nccl_msg("ncclGroupStart", r));
     NcclResult first_bad = 0;

@@ -1653,6 +1653,15 @@ struct pbf_ctx {
     struct ConsBatch { uint32_t first_level, n_levels, first, count; bool one_block; };
     std::vector<ConsBatch> cons_batches;
     uint32_t cons_max_particle = 0;
+    // native slab step (pbf_slab_attach / pbf_slab_step): exchange buffers owned by the ctx
+    pbf_comm* link_comm = nullptr;
+    int32_t link_left = -1, link_right = -1;
+    uint32_t link_max = 0;
+    float *x_mig[2] = {nullptr, nullptr}, *x_gh[2] = {nullptr, nullptr};      // out: records
+    float *x_rmig[2] = {nullptr, nullptr}, *x_rgh[2] = {nullptr, nullptr};    // in: records
+    float4 *x_hsend[2] = {nullptr, nullptr}, *x_hrecv[2] = {nullptr, nullptr};
+    uint32_t *x_counts = nullptr;       // device: 8 own counters + 4 received
+    uint32_t *x_host_counts = nullptr;  // pinned host mirror (12)
     bool owns_stream = true;
     bool uniform = false;      // every particle has uniform_mass (no per-neighbour mass gather)
     float uniform_mass = 0.f;
@@ -1882,6 +1891,20 @@ int download3(pbf_ctx* c, const float4* src, float* host) {
     return PBF_OK;
 }
 
+void free_link(pbf_ctx* c) {
+    for (int k = 0; k < 2; ++k) {
+        (void)hipFree(c->x_mig[k]); (void)hipFree(c->x_gh[k]); (void)hipFree(c->x_rmig[k]);
+        (void)hipFree(c->x_rgh[k]); (void)hipFree(c->x_hsend[k]); (void)hipFree(c->x_hrecv[k]);
+        c->x_mig[k] = c->x_gh[k] = c->x_rmig[k] = c->x_rgh[k] = nullptr;
+        c->x_hsend[k] = c->x_hrecv[k] = nullptr;
+    }
+    (void)hipFree(c->x_counts);
+    if (c->x_host_counts) (void)hipHostFree(c->x_host_counts);
+    c->x_counts = c->x_host_counts = nullptr;
+    c->link_comm = nullptr;
+    c->link_max = 0;
+}
+
 void free_constraints(pbf_ctx* c) {
     (void)hipFree(c->cons_p0); (void)hipFree(c->cons_p1); (void)hipFree(c->cons_level_start);
     (void)hipFree(c->slot_by_id); (void)hipFree(c->cons_rest); (void)hipFree(c->cons_stiff);
@@ -2063,6 +2086,7 @@ int pbf_destroy(pbf_ctx* c) {
     (void)hipFree(c->slab_cnt);
     free_boundary(c);
     free_constraints(c);
+    free_link(c);
     if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PBF_OK;
@@ -2720,6 +2744,124 @@ int pbf_slab_halo_exchange(pbf_ctx* c, pbf_comm* comm, int32_t what, int32_t lef
     rc = pbf_comm_batch(comm, (void*)c->stream, ops, 4);
     if (rc) return fail(c, rc, std::string("halo exchange: ") + pbf_comm_last_error(comm));
     return pbf_slab_unpack_halo(c, what, d_recv_left, r0, d_recv_right, r1);
+}
+
+int pbf_slab_attach(pbf_ctx* c, pbf_comm* comm, int32_t left_rank, int32_t right_rank,
+                    uint32_t max_records) {
+    ENTER(c);
+    if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
+    if (!comm) return fail(c, PBF_ERR_INVALID, "null communicator");
+    const int32_t world = pbf_comm_world(comm), me = pbf_comm_rank(comm);
+    if (left_rank >= world || right_rank >= world || left_rank == me || right_rank == me)
+        return fail(c, PBF_ERR_INVALID, "bad neighbour rank");
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    free_link(c);
+    if (!max_records) max_records = c->cap / 4 > 65536u ? c->cap / 4 : 65536u;
+    if (max_records > c->cap) max_records = c->cap;
+#define L_CK(call)                                                                       \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            free_link(c);                                                                \
+            return fail(c, PBF_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        }                                                                                \
+    } while (0)
+    for (int k = 0; k < 2; ++k) {
+        L_CK(dalloc(&c->x_mig[k], (size_t)max_records * PBF_RECORD_FLOATS));
+        L_CK(dalloc(&c->x_gh[k], (size_t)max_records * PBF_RECORD_FLOATS));
+        L_CK(dalloc(&c->x_rmig[k], (size_t)max_records * PBF_RECORD_FLOATS));
+        L_CK(dalloc(&c->x_rgh[k], (size_t)max_records * PBF_RECORD_FLOATS));
+        L_CK(dalloc(&c->x_hsend[k], (size_t)max_records));
+        L_CK(dalloc(&c->x_hrecv[k], (size_t)max_records));
+    }
+    L_CK(dalloc(&c->x_counts, (size_t)12));
+    L_CK(hipMemset(c->x_counts, 0, 12 * sizeof(uint32_t)));   // open ends stay 0 for good
+    L_CK(hipHostMalloc((void**)&c->x_host_counts, 12 * sizeof(uint32_t), hipHostMallocDefault));
+#undef L_CK
+    c->link_comm = comm;
+    c->link_left = left_rank;
+    c->link_right = right_rank;
+    c->link_max = max_records;
+    return PBF_OK;
+}
+
+// one PBF sub-step of this rank's slab, exchanges included: the protocol of
+// fluidsimulation_amd/slab.py::SlabGroup.step for one slab, issued from C++ so that the launches
+// behind the sub-step's one host synchronisation follow each other within microseconds
+int pbf_slab_step(pbf_ctx* c, float dt) {
+    ENTER(c);
+    if (!c->link_comm) return fail(c, PBF_ERR_INVALID, "pbf_slab_attach has not been called");
+    pbf_comm* comm = c->link_comm;
+    const int32_t L = c->link_left, R = c->link_right;
+    int rc = pbf_predict(c, dt);
+    if (rc) return rc;
+    if ((rc = pbf_slab_split(c, c->x_mig[0], c->x_mig[1], c->x_gh[0], c->x_gh[1], c->link_max, c->x_counts))) return rc;
+    // counts to the neighbours device-to-device, then the ONE read-back of the sub-step
+    {
+        uint32_t* d = c->x_counts;
+        pbf_p2p ops[4] = {{1, L, d + 2, L < 0 ? 0u : 8u}, {0, L, d + 8, L < 0 ? 0u : 8u},
+                          {1, R, d + 4, R < 0 ? 0u : 8u}, {0, R, d + 10, R < 0 ? 0u : 8u}};
+        rc = pbf_comm_batch(comm, (void*)c->stream, ops, 4);
+        if (rc) return fail(c, rc, std::string("count exchange: ") + pbf_comm_last_error(comm));
+        HIP_CK(c, hipMemcpyAsync(c->x_host_counts, d, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_CK(c, hipStreamSynchronize(c->stream));
+    }
+    const uint32_t* h = c->x_host_counts;
+    const uint32_t own[6] = {h[0], h[1], h[2], h[3], h[4], h[5]};
+    const uint32_t from_left[2] = {h[8], h[9]}, from_right[2] = {h[10], h[11]};   // {migrants, ghosts}
+    if ((rc = pbf_slab_split_done(c, own))) return rc;
+    if (from_left[0] > c->link_max || from_left[1] > c->link_max || from_right[0] > c->link_max ||
+        from_right[1] > c->link_max)
+        return fail(c, PBF_ERR_CAPACITY, "incoming migrants / ghosts exceed the exchange buffers (pbf_slab_attach max_records)");
+    {
+        const uint64_t rb = PBF_RECORD_FLOATS * sizeof(float);
+        pbf_p2p ops[8] = {{1, L, c->x_mig[0], own[2] * rb}, {0, L, c->x_rmig[0], from_left[0] * rb},
+                          {1, L, c->x_gh[0], own[3] * rb},  {0, L, c->x_rgh[0], from_left[1] * rb},
+                          {1, R, c->x_mig[1], own[4] * rb}, {0, R, c->x_rmig[1], from_right[0] * rb},
+                          {1, R, c->x_gh[1], own[5] * rb},  {0, R, c->x_rgh[1], from_right[1] * rb}};
+        if (L < 0) for (int k = 0; k < 4; ++k) ops[k].bytes = 0;
+        if (R < 0) for (int k = 4; k < 8; ++k) ops[k].bytes = 0;
+        rc = pbf_comm_batch(comm, (void*)c->stream, ops, 8);
+        if (rc) return fail(c, rc, std::string("payload exchange: ") + pbf_comm_last_error(comm));
+    }
+    if ((rc = pbf_slab_append_owned(c, c->x_rmig[0], L < 0 ? 0 : from_left[0], c->x_rmig[1], R < 0 ? 0 : from_right[0]))) return rc;
+    if ((rc = pbf_slab_append_ghosts(c, c->x_rgh[0], L < 0 ? 0 : from_left[1], c->x_rgh[1], R < 0 ? 0 : from_right[1]))) return rc;
+    if (c->bcount[0] > c->link_max || c->bcount[1] > c->link_max || c->ghost_count[0] > c->link_max ||
+        c->ghost_count[1] > c->link_max)
+        return fail(c, PBF_ERR_CAPACITY, "halo exceeds the exchange buffers (pbf_slab_attach max_records)");
+    if ((rc = pbf_build_grid(c))) return rc;
+    auto halo = [&](int32_t what) {
+        return pbf_slab_halo_exchange(c, comm, what, L, R, c->x_hsend[0], c->x_hsend[1], c->x_hrecv[0], c->x_hrecv[1]);
+    };
+    const bool vort = c->P.vorticity_eps != 0.f, xsph = c->P.xsph_c != 0.f, viscous = vort || xsph;
+    const int32_t layers = c->ghost_layers;
+    const bool local_sweeps = layers >= 2;
+    int32_t valid = layers;   // ghost layers whose data is still exact (slab.py, "communication-avoiding halo")
+    for (int32_t it = 0; it < c->iterations; ++it) {
+        if (local_sweeps && valid < 2) {
+            if ((rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
+            valid = layers;
+        }
+        if ((rc = pbf_solve_lambda(c, dt))) return rc;
+        if (!local_sweeps && (rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
+        if ((rc = pbf_solve_delta(c, dt))) return rc;
+        if (local_sweeps) valid -= 2;
+        else if (it + 1 < c->iterations && (rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
+    }
+    if (viscous && (rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
+    if ((rc = pbf_finalize_stage(c, 0, dt))) return rc;
+    if (vort) {
+        if ((rc = pbf_finalize_stage(c, 1, dt))) return rc;
+        if (!local_sweeps && (rc = halo(PBF_HALO_OMEGA))) return rc;
+        if ((rc = pbf_finalize_stage(c, 2, dt))) return rc;
+        if (xsph && (rc = halo(PBF_HALO_VELOCITY))) return rc;
+    }
+    if (xsph && (rc = pbf_finalize_stage(c, 3, dt))) return rc;
+    return PBF_OK;
+}
+
+uint32_t pbf_slab_owned_count(const pbf_ctx* c) {
+    return c ? c->n - c->ghost_count[0] - c->ghost_count[1] : 0;
 }
 
 int pbf_slab_export(pbf_ctx* c, void* d_records, uint32_t max_records, uint32_t* count) {

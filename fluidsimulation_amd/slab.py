@@ -181,7 +181,7 @@ class HipSlabBackend:
 
     def owned_count(self):
         """owned particles after the last sub-step (ghosts sit behind them until the next split)"""
-        return int(self.ctx.n) - self.gcount[0] - self.gcount[1]
+        return self.ctx.slab_owned_count()
 
     def build(self):
         self.ctx.build_grid()
@@ -557,7 +557,7 @@ class SlabSimulation:
     """What bench.py and multi-GPU callers use: this rank's slab of a scene, over RCCL."""
 
     def __init__(self, params: PbfParams, pos, mass, colliders, rank, world, device=0, vel=None,
-                 headroom=1.5, rebalance_every=0, ghost_layers=GHOST_LAYERS, transport="auto"):
+                 headroom=1.5, rebalance_every=0, ghost_layers=GHOST_LAYERS, transport="auto", native_step=True):
         import torch.distributed as dist
         planes = split_planes(pos, params.grid_spacing, world, min_width=2 * ghost_layers)
         self.planes = planes
@@ -582,6 +582,13 @@ class SlabSimulation:
         if exchange is None:
             exchange = TorchExchange(rank, world)
         self.group = SlabGroup([self.backend], exchange, int(params.solver_iterations))
+        # with the C-ABI transport the whole sub-step runs natively (pbf_slab_step): same
+        # protocol as SlabGroup.step, issued from C++
+        self.native = isinstance(exchange, P2PExchange) and native_step
+        if self.native:
+            self.backend.ctx.slab_attach(exchange.comm, -1 if rank == 0 else rank - 1,
+                                         -1 if rank == world - 1 else rank + 1, self.backend.max_records)
+            self.transport = "rccl (C ABI, native sub-step)"
         self.ctx = self.backend.ctx
         self.dist = dist
         self.rank, self.world = rank, world
@@ -589,7 +596,10 @@ class SlabSimulation:
         self.rebalance_every = rebalance_every
 
     def step(self, dt):
-        self.group.step(dt)
+        if self.native:
+            self.backend.ctx.slab_step(dt)
+        else:
+            self.group.step(dt)
         self.steps += 1
         if self.rebalance_every and self.steps % self.rebalance_every == 0:
             self.rebalance()

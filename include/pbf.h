@@ -347,6 +347,11 @@ typedef struct pbf_p2p {
     uint64_t bytes;  /* 0 = skipped on both ends (sizes are agreed beforehand) */
 } pbf_p2p;
 int pbf_comm_unique_id(void* id_out);
+/* an id that selects the in-process loopback transport instead of RCCL: the `world` ranks are
+ * threads of ONE process (each with its own ctx and stream, possibly on one GPU); same matching
+ * rule and stream semantics, implemented with events and device-to-device copies.  For tests of
+ * the multi-rank protocol where only one GPU is available. */
+int pbf_comm_local_id(void* id_out);
 int pbf_comm_create(const void* id, int32_t rank, int32_t world, int32_t device, pbf_comm** out);
 int pbf_comm_destroy(pbf_comm* comm);
 int32_t pbf_comm_rank(const pbf_comm* comm);
@@ -362,6 +367,20 @@ int pbf_comm_batch(pbf_comm* comm, void* hip_stream, const pbf_p2p* ops, uint32_
 int pbf_slab_halo_exchange(pbf_ctx* ctx, pbf_comm* comm, int32_t what, int32_t left_rank,
                            int32_t right_rank, void* d_send_left, void* d_send_right,
                            void* d_recv_left, void* d_recv_right);
+
+/* the native slab runtime: attach a communicator and the neighbour ranks (< 0 = open end) to a
+ * slab ctx -- the ctx allocates its exchange buffers (max_records particles per message; 0 =
+ * capacity / 4) -- then pbf_slab_step runs one whole sub-step of the slab INCLUDING the
+ * exchanges: predict, split, counts to the neighbours, the sub-step's one host synchronisation,
+ * migrants + ghost planes, grid, iterations x { lambda, delta-p } with a ghost refresh only when
+ * fewer than two valid ghost layers are left, velocity update (+ vorticity / XSPH stages).
+ * Every rank of the communicator calls it once per sub-step.  The ctx's bounds may be moved
+ * between sub-steps (pbf_slab_set_bounds: re-balancing). */
+int pbf_slab_attach(pbf_ctx* ctx, pbf_comm* comm, int32_t left_rank, int32_t right_rank,
+                    uint32_t max_records);
+int pbf_slab_step(pbf_ctx* ctx, float dt);
+/* owned particles after the last sub-step (its ghosts sit behind them until the next split) */
+uint32_t pbf_slab_owned_count(const pbf_ctx* ctx);
 
 /* self-test (no reference counterpart): compares the kernels' 6-instruction correctly rounded
  * fp32 square root with the compiler's sqrtf over EVERY non-negative float; *mismatches must

@@ -98,3 +98,65 @@ def test_fused_halo_exchange_mirrors_the_boundary_planes():
     oa, ob = np.argsort(S.record_ids(ra)), np.argsort(S.record_ids(rb))
     assert np.array_equal(ra[oa], rb[ob])
     assert np.isfinite(ra).all()
+
+
+def _native_rank(rank, world, uid, p, pos, mass, cols, vel, planes, layers, steps, out, errs, rebalance):
+    try:
+        import torch
+        from fluidsimulation_amd import slab as S
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            q = S.rank_local_params(p, pos, planes, rank, world, headroom=3.0, ghost_layers=layers)
+            b = S.HipSlabBackend(q, cols, mass, planes[rank], planes[rank + 1], device=0, ghost_layers=layers)
+            S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
+                       p.grid_spacing, vel=vel)
+            comm = RcclComm(uid, rank, world, 0)
+            b.ctx.slab_attach(comm, -1 if rank == 0 else rank - 1, -1 if rank == world - 1 else rank + 1,
+                              b.max_records)
+            my_planes = list(planes)
+            for s in range(steps):
+                b.ctx.slab_step(DT)
+                if rebalance and s == 2:      # every rank moves the same plane by one cell
+                    my_planes[1] += 1
+                    b.set_bounds(my_planes[rank], my_planes[rank + 1])
+            b.sync()
+            out[rank] = b.export()
+    except Exception as e:  # noqa: BLE001
+        errs.append((rank, repr(e)))
+
+
+@pytest.mark.parametrize("world,layers,viscous,rebalance", [(2, 2, False, False), (3, 2, False, True),
+                                                          (3, 4, False, False), (2, 4, True, False),
+                                                          (2, 1, True, False)])
+def test_native_slab_step_over_loopback_equals_single_domain(world, layers, viscous, rebalance):
+    """pbf_slab_step (the native sub-step that runs over RCCL on the multi-GPU node) with `world`
+    rank threads on this one GPU over the library's loopback transport (same matching rule and
+    stream semantics as the RCCL path): bit-identical with the single-domain oracle"""
+    import threading
+    from fluidsimulation_amd import slab as S
+    from oracle import pyoracle
+    from tests.slab_common import slab_scene
+    kw = dict(xsph_c=0.01, vorticity_eps=2e-6, vel_scale=2.0) if viscous else {}
+    p, pos, mass, cols, vel = slab_scene(nx=60 if layers == 4 else 30, ny=6, nz=6, iterations=3, **kw)
+    steps = 6
+    planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    uid = RcclComm.local_id()
+    out, errs = {}, []
+    ts = [threading.Thread(target=_native_rank, args=(r, world, uid, p, pos, mass, cols, vel, planes, layers,
+                                                      steps, out, errs, rebalance)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs
+    rec = np.concatenate([out[r] for r in range(world)], axis=0)
+    order = np.argsort(S.record_ids(rec))
+    o = pyoracle.Oracle(p)
+    o.upload(pos, vel=vel, uniform_mass=mass)
+    o.set_colliders(cols)
+    for _ in range(steps):
+        o.step(DT)
+    op, ov, _, _ = o.download()
+    assert rec.shape[0] == pos.shape[0]
+    assert np.array_equal(rec[order, 0:3], op) and np.array_equal(rec[order, 4:7], ov)
+    assert all(out[r].shape[0] > 0 for r in range(world))

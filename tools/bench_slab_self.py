@@ -54,6 +54,26 @@ def mirror(base):
     return Mirror
 
 
+def run_native_open(layers, steps=50, warm=10, block=(100, 100, 100)):
+    """pbf_slab_step with a one-rank communicator and open ends: the native pipeline (split, the
+    one host synchronisation, grid, sweeps) without any neighbour -- what the C++ sub-step costs
+    over the plain single-ctx step before exchanges are added"""
+    from fluidsimulation_amd.binding import RcclComm
+    p, pos, mass, cols = scenes.dam_break(*block, iterations=4)
+    q = S.rank_local_params(p, pos, [S.INT32_MIN, S.INT32_MAX], 0, 1, ghost_layers=layers)
+    b = S.HipSlabBackend(q, cols, mass, S.INT32_MIN, S.INT32_MAX, device=0, ghost_layers=layers)
+    S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), S.INT32_MIN, S.INT32_MAX, p.grid_spacing)
+    b.ctx.slab_attach(RcclComm(RcclComm.unique_id(), 0, 1, 0), -1, -1, b.max_records)
+    for _ in range(warm):
+        b.ctx.slab_step(DT)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        b.ctx.slab_step(DT)
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / steps
+    print(f"native sub-step, no neighbours: {t*1e3:.3f} ms/step", flush=True)
+    del b
+
+
 def run(layers, transport, steps=50, warm=10, block=(100, 100, 100)):
     p, pos, mass, cols = scenes.dam_break(*block, iterations=4)
     SHIFT[0] = 64.0 * float(p.grid_spacing)
@@ -118,6 +138,7 @@ if __name__ == "__main__":
     for _ in range(50): g.step(DT)
     g.sync(); print(f"single ctx: {(time.perf_counter()-t0)/50*1e3:.3f} ms/step", flush=True)
     del g
+    run_native_open(2)
     for tr in transports:
         for L in [int(a) for a in args] or [2]:
             run(L, tr)

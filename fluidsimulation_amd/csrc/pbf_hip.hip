@@ -344,12 +344,34 @@ __global__ __launch_bounds__(BLOCK) void k_scan_sums(uint32_t* __restrict__ tile
 
 // writes cell_start (exclusive prefix), a cursor copy for the scatter, and clears the
 // histogram for the next sub-step (so no per-step memset is needed)
+// FOLD: tile_sums holds the raw per-tile totals and every workgroup sums the ones in front of it
+// itself (grids of up to FOLD_MAX_TILES tiles: saves the single-workgroup k_scan_sums launch);
+// otherwise tile_sums already holds exclusive prefixes.  Workgroup 0 also clears the device
+// flags of the neighbour build that follows (no per-step memset).
+constexpr uint32_t FOLD_MAX_TILES = 2048;
+
+template <bool FOLD>
 __global__ __launch_bounds__(BLOCK) void k_scan_apply(uint32_t* __restrict__ count, uint32_t ncell,
                                                       const uint32_t* __restrict__ tile_sums,
                                                       uint32_t* __restrict__ cell_start,
-                                                      uint32_t* __restrict__ cursor) {
+                                                      uint32_t* __restrict__ cursor,
+                                                      DevFlags* __restrict__ flags) {
     static_assert(SCAN_ITEMS == 8, "vector path below moves two uint4 per thread");
     __shared__ uint32_t lds_waves[BLOCK / 64];
+    if (flags && blockIdx.x == 0 && threadIdx.x == 0) {
+        flags->neighbor_overflow = 0u;
+        flags->max_count = 0u;
+    }
+    uint32_t tile_base;
+    if (FOLD) {
+        uint32_t part = 0;
+        for (uint32_t t = threadIdx.x; t < blockIdx.x; t += BLOCK) part += tile_sums[t];
+        uint32_t tot;
+        block_excl_scan(part, lds_waves, tot);
+        tile_base = tot;
+    } else {
+        tile_base = tile_sums[blockIdx.x];
+    }
     uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t c[SCAN_ITEMS];
     load_items(count, base, ncell, c);
@@ -357,7 +379,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(uint32_t* __restrict__ cou
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) s += c[k];
     uint32_t total;
-    uint32_t ex = block_excl_scan(s, lds_waves, total) + tile_sums[blockIdx.x];
+    uint32_t ex = block_excl_scan(s, lds_waves, total) + tile_base;
     uint32_t e[SCAN_ITEMS];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
@@ -1835,9 +1857,14 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true) {
     {
         PhaseScope ps(c, PH_SORT);
         k_scan_tile_sums<<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums);
-        k_scan_sums<<<1, BLOCK, 0, c->stream>>>(c->tile_sums, c->ntiles);
-        k_scan_apply<<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
-                                                         c->cell_start, c->cursor);
+        if (c->ntiles <= FOLD_MAX_TILES) {
+            k_scan_apply<true><<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
+                                                                   c->cell_start, c->cursor, c->flags);
+        } else {
+            k_scan_sums<<<1, BLOCK, 0, c->stream>>>(c->tile_sums, c->ntiles);
+            k_scan_apply<false><<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
+                                                                    c->cell_start, c->cursor, c->flags);
+        }
         if (n) {
             const int s = c->cur, d = 1 - c->cur;
             const int ps_ = c->prd_cur, pd = (c->prd_cur + 1) % 3;
@@ -1857,8 +1884,7 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true) {
         return PBF_OK;
     }
     if (n) {
-        PhaseScope ps(c, PH_NEIGHBORS);
-        HIP_CK(c, hipMemsetAsync(c->flags, 0, sizeof(DevFlags), c->stream));
+        PhaseScope ps(c, PH_NEIGHBORS);   // the device flags were cleared by k_scan_apply
         k_neighbors<true><<<nblocks(n), BLOCK, 0, c->stream>>>(
             c->prd[c->prd_cur], c->prd[c->prd_cur], c->cell_start, n, c->cap, c->K, G,
             c->P.effective_radius * c->P.effective_radius, c->nbr, c->nbr_count, c->flags);
@@ -2246,8 +2272,8 @@ int pbf_set_boundary(pbf_ctx* c, const float* pos, const float* mass, float unif
     k_rekey<<<nbb, BLOCK, 0, c->stream>>>(raw, key, c->cell_count, nb, G);
     k_scan_tile_sums<<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums);
     k_scan_sums<<<1, BLOCK, 0, c->stream>>>(c->tile_sums, c->ntiles);
-    k_scan_apply<<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
-                                                     c->b_cell_start, c->cursor);
+    k_scan_apply<false><<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
+                                                            c->b_cell_start, c->cursor, nullptr);
     k_scatter<<<nbb, BLOCK, 0, c->stream>>>(key, ident, c->cursor, nb, tsrc, tid);
     k_boundary_reorder<<<nbb, BLOCK, 0, c->stream>>>(key, c->b_cell_start, tsrc, tid, nb, raw, c->bprd,
                                                      c->bmass, c->bid);

@@ -160,3 +160,56 @@ def test_native_slab_step_over_loopback_equals_single_domain(world, layers, visc
     assert rec.shape[0] == pos.shape[0]
     assert np.array_equal(rec[order, 0:3], op) and np.array_equal(rec[order, 4:7], ov)
     assert all(out[r].shape[0] > 0 for r in range(world))
+
+
+def test_c4_16m_particles_four_native_slabs_equal_one_ctx():
+    """C4 at full size (256x250x250 = 16 000 000 particles, 4 iterations): four slabs stepped by
+    pbf_slab_step (rank threads over the loopback transport, all on this one GPU) against ONE
+    ctx stepping the whole scene -- bit-identical after two sub-steps; plus the size-independent
+    structure checks on the single ctx (sortedness of the cell order, scene statistics)"""
+    import threading
+    import torch
+    from fluidsimulation_amd import slab as S
+    from fluidsimulation_amd import scenes
+    p, pos, mass, cols = scenes.dam_break(256, 250, 250, iterations=4)
+    n = pos.shape[0]
+    assert n == 16_000_000
+    steps, world, layers = 2, 4, 4
+    # -- one ctx
+    g = PbfContext(p, device=0)
+    g.upload(pos, uniform_mass=mass)
+    g.set_colliders(cols)
+    g.predict(DT); g.build_grid()
+    xyz, key, sid, start = g.cells()
+    ks = key[sid]
+    assert np.all(ks[1:] >= ks[:-1])
+    same = ks[1:] == ks[:-1]
+    assert np.all(sid[1:][same] > sid[:-1][same])
+    assert int(start[-1]) == n
+    del xyz, key, sid, start, ks, same
+    g.solve(DT); g.finalize(DT)
+    for _ in range(steps - 1):
+        g.step(DT)
+    g.sync()
+    st = g.stats()
+    assert st.n == n and st.nonfinite == 0 and st.neighbor_overflow == 0
+    assert 15.0 < st.mean_neighbor_count < 30.0
+    p1, v1, _ = g.download()
+    del g
+    torch.cuda.empty_cache()
+    # -- four native slabs
+    planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    uid = RcclComm.local_id()
+    out, errs = {}, []
+    vel = np.zeros_like(pos)
+    ts = [threading.Thread(target=_native_rank, args=(r, world, uid, p, pos, mass, cols, vel, planes, layers,
+                                                      steps, out, errs, False)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not errs, errs
+    rec = np.concatenate([out[r] for r in range(world)], axis=0)
+    assert rec.shape[0] == n
+    order = np.argsort(S.record_ids(rec))
+    assert np.array_equal(rec[order, 0:3], p1) and np.array_equal(rec[order, 4:7], v1)

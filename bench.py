@@ -239,6 +239,10 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        import torch as _t
+        _t.cuda.synchronize()
+        dist.barrier()
+        sim.close()
         dist.destroy_process_group()
 
 

@@ -641,5 +641,15 @@ class SlabSimulation:
     def sync(self):
         self.backend.sync()
 
+    def close(self):
+        """drains the stream and drops the library's RCCL communicator; call before
+        torch.distributed.destroy_process_group() (every rank)"""
+        try:
+            self.backend.sync()
+        finally:
+            comm = getattr(self.group.exchange, "comm", None)
+            if comm is not None and hasattr(comm, "close"):
+                comm.close()
+
     def export(self):
         return self.group.export()

@@ -213,3 +213,38 @@ def test_c4_16m_particles_four_native_slabs_equal_one_ctx():
     assert rec.shape[0] == n
     order = np.argsort(S.record_ids(rec))
     assert np.array_equal(rec[order, 0:3], p1) and np.array_equal(rec[order, 4:7], v1)
+
+
+def test_slab_simulation_bootstraps_the_native_path_on_an_nccl_group():
+    """what bench.py --gpus N does on every rank, here with a world of one: the RCCL unique id
+    travels over the torch.distributed (nccl) group, the communicator is created through the C
+    ABI, the ctx attaches it and steps natively; equal to the plain ctx"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from fluidsimulation_amd.slab import SlabSimulation
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        p, pos, mass, cols = scenes.dam_break(20, 16, 12, iterations=4)
+        sim = SlabSimulation(p, pos, mass, cols, rank=0, world=1, device=0, ghost_layers=4)
+        assert sim.native and "native" in sim.transport
+        g = PbfContext(p, device=0)
+        g.upload(pos, uniform_mass=mass)
+        g.set_colliders(cols)
+        for _ in range(5):
+            sim.step(DT)
+            g.step(DT)
+        sim.sync()
+        st = sim.stats()
+        assert st["n"] == pos.shape[0] and st["nonfinite"] == 0
+        ids, gpos, gvel = sim.export()
+        p1, v1, _ = g.download()
+        assert np.array_equal(gpos, p1) and np.array_equal(gvel, v1)
+        assert sim.owned_counts() == [pos.shape[0]]
+        sim.close()
+    finally:
+        dist.destroy_process_group()

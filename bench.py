@@ -190,11 +190,16 @@ def main():
             if calls:
                 phases[name] = {"ms_per_launch": ms / calls, "launches_per_step": calls / ksteps,
                                 "ms_per_step": ms / ksteps}
-        cand = {k: v for k, v in phases.items() if k in ALGO_BYTES}
+        algo = dict(ALGO_BYTES)
+        if "finalize" not in phases and "delta" in phases:
+            # the velocity update rides along with the last delta-p launch of a sub-step (k_delta<FINAL>):
+            # its 48 algorithmic bytes are spread over the sub-step's delta launches
+            algo["delta"] = ALGO_BYTES["delta"] + ALGO_BYTES["finalize"] / phases["delta"]["launches_per_step"]
+        cand = {k: v for k, v in phases.items() if k in algo}
         if cand:
             dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
             per_launch_s = cand[dom]["ms_per_launch"] * 1e-3
-            achieved = ALGO_BYTES[dom] * n_local / per_launch_s / 1e9
+            achieved = algo[dom] * n_local / per_launch_s / 1e9
             tr = pmc_traffic(dom)
             traffic = None
             # the PMC summary derives its particle count from SQ_WAVES x 64 (rounded up per block)
@@ -203,8 +208,8 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-                        "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * n_local,
-                        "algorithmic_bytes_per_particle": ALGO_BYTES[dom],
+                        "algorithmic_bytes_per_launch": algo[dom] * n_local,
+                        "algorithmic_bytes_per_particle": algo[dom],
                         "avg_launch_ms": cand[dom]["ms_per_launch"], "particles_per_launch": n_local}
 
     if rank == 0:

@@ -789,7 +789,11 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __r
 // Jacobi hand-over copy directly (UpdatePredictPosition, :714-721), plus the build-side
 // container clamp.  Accumulates onto new_i in neighbour-row order like the reference.
 
-template <int GRAD, bool BND>
+// FINAL: the last iteration of a sub-step without constraints / viscosity also performs
+// ParticleSet::Update (k_finalize: v = (new - p) / dt; p = new) for its own particle -- the
+// streaming pass over pos / vel / prd that k_finalize would make rides along with a kernel that
+// is instruction-bound anyway.  No other thread reads pos or vel in this kernel.
+template <int GRAD, bool BND, bool FINAL>
 __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
                                                  float4* __restrict__ prd_out,
                                                  const uint32_t* __restrict__ nbr,
@@ -799,7 +803,9 @@ __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
                                                  int container, float3_ cmin, float3_ cmax,
                                                  const float4* __restrict__ bprd,
                                                  const uint32_t* __restrict__ fb,
-                                                 const uint32_t* __restrict__ fb_count) {
+                                                 const uint32_t* __restrict__ fb_count,
+                                                 float4* __restrict__ pos, float4* __restrict__ vel,
+                                                 float dt) {
     uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float inv_rho0 = 1.f / *rho0_ptr;
@@ -837,6 +843,11 @@ __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
         nz = nz > cmax.z ? cmax.z : nz;
     }
     prd_out[i] = make_float4(nx, ny, nz, xi.w);
+    if (FINAL) {
+        const float4 p = pos[i];
+        vel[i] = make_float4((nx - p.x) / dt, (ny - p.y) / dt, (nz - p.z) / dt, 0.f);
+        pos[i] = make_float4(nx, ny, nz, p.w);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -2398,7 +2409,7 @@ int pbf_compute_rest_density(pbf_ctx* c) {
     return PBF_OK;
 }
 
-static int solve_half(pbf_ctx* c, int half, float dt) {
+static int solve_half(pbf_ctx* c, int half, float dt, bool fuse_finalize = false) {
     const KernConsts kc = make_kern(c->P, dt);
     const uint32_t nb = nblocks(c->n);
     const bool spiky = c->P.gradient_kernel == PBF_GRAD_SPIKY;
@@ -2446,19 +2457,31 @@ static int solve_half(pbf_ctx* c, int half, float dt) {
         float3_ cmin = {c->P.container_min[0], c->P.container_min[1], c->P.container_min[2]};
         float3_ cmax = {c->P.container_max[0], c->P.container_max[1], c->P.container_max[2]};
         float4* y = c->prd[(c->prd_cur + 1) % 3];
-#define LAUNCH_DELTA(G, B)                                                                        \
-    k_delta<G, B><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n, c->cap, kc, c->rho0, \
-                                               c->P.container_enabled, cmin, cmax, c->bprd, c->fb, \
-                                               c->fb_count)
-        if (!spiky && !c->nb) LAUNCH_DELTA(PBF_GRAD_POLY6, false);
-        else if (!spiky) LAUNCH_DELTA(PBF_GRAD_POLY6, true);
-        else if (!c->nb) LAUNCH_DELTA(PBF_GRAD_SPIKY, false);
-        else LAUNCH_DELTA(PBF_GRAD_SPIKY, true);
+#define LAUNCH_DELTA(G, B, F)                                                                     \
+    k_delta<G, B, F><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n, c->cap, kc,   \
+                                                  c->rho0, c->P.container_enabled, cmin, cmax,    \
+                                                  c->bprd, c->fb, c->fb_count, c->pos[c->cur],    \
+                                                  c->vel[c->cur], dt)
+#define LAUNCH_DELTA_F(G, B)                  \
+    do {                                      \
+        if (fuse_finalize) LAUNCH_DELTA(G, B, true); \
+        else LAUNCH_DELTA(G, B, false);       \
+    } while (0)
+        if (!spiky && !c->nb) LAUNCH_DELTA_F(PBF_GRAD_POLY6, false);
+        else if (!spiky) LAUNCH_DELTA_F(PBF_GRAD_POLY6, true);
+        else if (!c->nb) LAUNCH_DELTA_F(PBF_GRAD_SPIKY, false);
+        else LAUNCH_DELTA_F(PBF_GRAD_SPIKY, true);
+#undef LAUNCH_DELTA_F
 #undef LAUNCH_DELTA
         c->prd_cur = (c->prd_cur + 1) % 3;
     }
     LAUNCH_CK(c);
     return PBF_OK;
+}
+
+// whether the sub-step's velocity update can ride along with the last delta-p kernel
+static bool can_fuse_finalize(const pbf_ctx* c) {
+    return c->iterations > 0 && c->n && !c->ncons && c->P.vorticity_eps == 0.f && c->P.xsph_c == 0.f;
 }
 
 int pbf_solve(pbf_ctx* c, int32_t iterations, float dt) {
@@ -2863,6 +2886,7 @@ int pbf_slab_step(pbf_ctx* c, float dt) {
     const int32_t layers = c->ghost_layers;
     const bool local_sweeps = layers >= 2;
     int32_t valid = layers;   // ghost layers whose data is still exact (slab.py, "communication-avoiding halo")
+    const bool fused = can_fuse_finalize(c);
     for (int32_t it = 0; it < c->iterations; ++it) {
         if (local_sweeps && valid < 2) {
             if ((rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
@@ -2870,10 +2894,16 @@ int pbf_slab_step(pbf_ctx* c, float dt) {
         }
         if ((rc = pbf_solve_lambda(c, dt))) return rc;
         if (!local_sweeps && (rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
-        if ((rc = pbf_solve_delta(c, dt))) return rc;
+        const bool last = it + 1 == c->iterations;
+        if (last && fused) {
+            if (c->n && (rc = solve_half(c, 1, dt, true))) return rc;
+        } else if ((rc = pbf_solve_delta(c, dt))) {
+            return rc;
+        }
         if (local_sweeps) valid -= 2;
-        else if (it + 1 < c->iterations && (rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
+        else if (!last && (rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
     }
+    if (fused) return PBF_OK;
     if (viscous && (rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
     if ((rc = pbf_finalize_stage(c, 0, dt))) return rc;
     if (vort) {
@@ -2921,6 +2951,13 @@ int pbf_step(pbf_ctx* c, float dt) {
         rc = pbf_compute_rest_density(c);
         if (rc) return rc;
         c->first_frame = false;
+    }
+    if (can_fuse_finalize(c)) {
+        for (int32_t it = 0; it < c->iterations; ++it) {
+            if ((rc = solve_half(c, 0, dt))) return rc;
+            if ((rc = solve_half(c, 1, dt, it + 1 == c->iterations))) return rc;
+        }
+        return PBF_OK;
     }
     rc = pbf_solve(c, c->iterations, dt);
     if (rc) return rc;

@@ -38,18 +38,23 @@ ALGO_BYTES_SUBSTEP_4IT = 382
 ALGO_BYTES_PER_ITER = 46           # 18 + 28
 
 
-def pmc_traffic(kernel_phase):
+def pmc_traffic(kernel_phase, iters=4):
     """HBM bytes per launch of the phase's kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_latest.json, written by tools/summarize_prof.py): FETCH_SIZE counts 64-B
     requests at half their size for wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM;
     calibrated on k_finalize: 32 MB read -> 16 MB counted), WRITE_SIZE is exact; both in KiB."""
     f = ROOT / "profiles" / "pmc_latest.json"
-    names = {"lambda": "k_lambda<true, 0, false>", "delta": "k_delta<0, false>", "predict": "k_predict",
+    names = {"lambda": "k_lambda<true, 0, false>", "delta": "k_delta<0, false, false>", "predict": "k_predict",
              "finalize": "k_finalize", "neighbors": "k_neighbors<true>"}
     try:
         d = json.loads(f.read_text())
         k = d["kernels"][names[kernel_phase]]
-        return {"bytes_per_launch": (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0,
+        nbytes = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        last = d["kernels"].get("k_delta<0, false, true>")
+        if kernel_phase == "delta" and last and iters > 0:
+            # the sub-step's last delta-p launch also carries the velocity update
+            nbytes = ((iters - 1) * nbytes + (2.0 * last["FETCH_SIZE"] + last["WRITE_SIZE"]) * 1024.0) / iters
+        return {"bytes_per_launch": nbytes,
                 "particles_per_launch": d["particles_per_launch"], "source": str(f.relative_to(ROOT))}
     except Exception:
         return None
@@ -200,7 +205,7 @@ def main():
             dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
             per_launch_s = cand[dom]["ms_per_launch"] * 1e-3
             achieved = algo[dom] * n_local / per_launch_s / 1e9
-            tr = pmc_traffic(dom)
+            tr = pmc_traffic(dom, a.iters)
             traffic = None
             # the PMC summary derives its particle count from SQ_WAVES x 64 (rounded up per block)
             if tr and abs(tr["particles_per_launch"] - n_local) < 1024:

@@ -27,8 +27,10 @@ def main():
     for k in agg:
         out[k] = {c: agg[k][c] / max(1, calls[k][c]) for c in agg[k]}   # per-launch averages
     n = None
-    if "k_finalize" in out and "SQ_WAVES" in out["k_finalize"]:
-        n = int(round(out["k_finalize"]["SQ_WAVES"] * 64))   # one thread per particle, wave64
+    for ref in ("k_predict", "k_finalize"):                   # one thread per particle, wave64
+        if ref in out and "SQ_WAVES" in out[ref]:
+            n = int(round(out[ref]["SQ_WAVES"] * 64))
+            break
     print(json.dumps({"particles_per_launch": n, "units": "per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB",
                       "kernels": out}, indent=1, sort_keys=True))
 

@@ -1831,6 +1831,7 @@ struct PhaseScope {
 int validate_params(const pbf_params& P, std::string& why) {
     if (P.abi_version != PBF_ABI_VERSION) { why = "abi_version mismatch"; return PBF_ERR_INVALID; }
     if (P.capacity == 0) { why = "capacity must be > 0"; return PBF_ERR_INVALID; }
+    if (P.capacity > (1u << 28)) { why = "capacity must not exceed 2^28 particles per ctx (32-bit gather offsets)"; return PBF_ERR_INVALID; }
     if (P.max_neighbors == 0 || P.max_neighbors > 1024) { why = "max_neighbors out of range"; return PBF_ERR_INVALID; }
     for (int a = 0; a < 3; ++a)
         if (P.grid_dim[a] < 3 || P.grid_dim[a] > 4096) { why = "grid_dim must be in [3, 4096]"; return PBF_ERR_INVALID; }

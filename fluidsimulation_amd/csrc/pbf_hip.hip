@@ -217,6 +217,24 @@ __device__ __forceinline__ void collide(const ColliderSet& cs, float px, float p
     }
 }
 
+// a6 + a7 for one particle: PredictPositions then the collider loop
+__device__ __forceinline__ void predict_one(const float4& p, const float4& v, float dt, float gx,
+                                            float gy, float gz, const ColliderSet& cs, float& vx,
+                                            float& vy, float& vz, float& qx, float& qy, float& qz) {
+    float m = p.w;
+    float minv = 1.f / m;  // m_massInv, Particle.cpp:184
+    // m_force = m_mass * vec3(0, g, 0); v = v + dt * massInv * force
+    float fx = m * gx, fy = m * gy, fz = m * gz;
+    float s = dt * minv;
+    vx = v.x + s * fx;
+    vy = v.y + s * fy;
+    vz = v.z + s * fz;
+    qx = p.x + dt * vx;
+    qy = p.y + dt * vy;
+    qz = p.z + dt * vz;
+    collide(cs, p.x, p.y, p.z, dt, vx, vy, vz, qx, qy, qz);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_predict(const float4* __restrict__ pos,
                                                    float4* __restrict__ vel,
                                                    float4* __restrict__ prd,
@@ -230,14 +248,8 @@ __global__ __launch_bounds__(BLOCK) void k_predict(const float4* __restrict__ po
     if (active) {
         float4 p = pos[i];
         float4 v = vel[i];
-        float m = p.w;
-        float minv = 1.f / m;  // m_massInv, Particle.cpp:184
-        // m_force = m_mass * vec3(0, g, 0); v = v + dt * massInv * force
-        float fx = m * gx, fy = m * gy, fz = m * gz;
-        float s = dt * minv;
-        float vx = v.x + s * fx, vy = v.y + s * fy, vz = v.z + s * fz;
-        float qx = p.x + dt * vx, qy = p.y + dt * vy, qz = p.z + dt * vz;
-        collide(cs, p.x, p.y, p.z, dt, vx, vy, vz, qx, qy, qz);
+        float vx, vy, vz, qx, qy, qz;
+        predict_one(p, v, dt, gx, gy, gz, cs, vx, vy, vz, qx, qy, qz);
         vel[i] = make_float4(vx, vy, vz, 0.f);
         prd[i] = make_float4(qx, qy, qz, 0.f);
         k = cell_key(G, floor_cell(qx, G.spacing), floor_cell(qy, G.spacing),
@@ -251,8 +263,8 @@ __global__ __launch_bounds__(BLOCK) void k_predict(const float4* __restrict__ po
 __global__ __launch_bounds__(BLOCK) void k_rekey(const float4* __restrict__ prd,
                                                  uint32_t* __restrict__ key,
                                                  uint32_t* __restrict__ cell_count, uint32_t n,
-                                                 GridConsts G) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+                                                 GridConsts G, uint32_t first = 0) {
+    uint32_t i = first + blockIdx.x * BLOCK + threadIdx.x;
     const bool active = i < n;
     uint32_t k = 0xffffffffu;
     if (active) {
@@ -1325,6 +1337,17 @@ constexpr int SPLIT_TILES = SPLIT_ITEMS * (BLOCK / 64);   // wave-sized tiles pe
 // both) and remember their compacted index for the halo refreshes.
 // Same-address atomics retire about one per 10 ns, so a block classifies SPLIT_CHUNK particles,
 // scans its wave tiles in LDS and reserves its output ranges with ONE atomic per counter.
+// PREDICT: the kernel also IS the sub-step's predict + collide pass (k_predict): it reads the old
+// pos / vel, and what it writes (and what it classifies on) is the predicted state -- the
+// stand-alone k_predict launch and one round trip of vel / prd through HBM disappear.
+// Stayers also get their cell key and histogram entry here (as k_predict does for a single ctx),
+// so only the particles appended afterwards (migrants in, ghosts) are keyed by k_rekey.
+struct PredictArgs {
+    float dt, gx, gy, gz;
+    ColliderSet cs;
+};
+
+template <bool PREDICT>
 __global__ __launch_bounds__(BLOCK) void k_slab_split(
     const float4* __restrict__ pos, const float4* __restrict__ vel, const float4* __restrict__ prd,
     const uint32_t* __restrict__ id, uint32_t n, float spacing, int32_t x_lo, int32_t x_hi,
@@ -1332,12 +1355,26 @@ __global__ __launch_bounds__(BLOCK) void k_slab_split(
     float4* __restrict__ vel_o, float4* __restrict__ prd_o, uint32_t* __restrict__ id_o,
     float* __restrict__ mig0, float* __restrict__ mig1, float* __restrict__ gh0,
     float* __restrict__ gh1, uint32_t max_records, uint32_t* __restrict__ blist0,
-    uint32_t* __restrict__ blist1, uint32_t* __restrict__ cnt) {
+    uint32_t* __restrict__ blist1, uint32_t* __restrict__ cnt, uint32_t* __restrict__ key_o,
+    uint32_t* __restrict__ cell_count, GridConsts G, PredictArgs A) {
     __shared__ uint32_t tile[3][SPLIT_TILES];
     __shared__ uint32_t block_base[3];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t chunk0 = blockIdx.x * SPLIT_CHUNK;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // the state a particle leaves this kernel with: (pos, velocity, predicted position)
+    auto state = [&](uint32_t i, float4& p, float4& v, float4& q) {
+        p = pos[i];
+        v = vel[i];
+        if (PREDICT) {
+            float vx, vy, vz, qx, qy, qz;
+            predict_one(p, v, A.dt, A.gx, A.gy, A.gz, A.cs, vx, vy, vz, qx, qy, qz);
+            v = make_float4(vx, vy, vz, 0.f);
+            q = make_float4(qx, qy, qz, 0.f);
+        } else {
+            q = prd[i];
+        }
+    };
     // per item: bits 0-1 class (0 none, 1 stay, 2 to the left, 3 to the right), bit 2 / 3 = in
     // the left / right boundary planes
     uint32_t flags = 0;
@@ -1349,7 +1386,15 @@ __global__ __launch_bounds__(BLOCK) void k_slab_split(
         if (i < n) pid = id[i];
         uint32_t f = 0;
         if (!(pid & GHOST_BIT)) {
-            const int32_t cx = floor_cell(prd[i].x, spacing);
+            float qx;
+            if (PREDICT) {
+                float4 p, v, q;
+                state(i, p, v, q);
+                qx = q.x;
+            } else {
+                qx = prd[i].x;
+            }
+            const int32_t cx = floor_cell(qx, spacing);
             if (cx < x_lo) {
                 f = 2;
                 too_far += (int64_t)cx < (int64_t)x_lo - (hi0 - lo0);
@@ -1393,16 +1438,26 @@ __global__ __launch_bounds__(BLOCK) void k_slab_split(
         const uint32_t f = (flags >> (4 * k)) & 15u;
         const bool stay = (f & 3u) == 1u, in0 = f & 4u, in1 = f & 8u;
         const unsigned long long ms = __ballot(stay), m0 = __ballot(in0), m1 = __ballot(in1);
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), v = p, q = p;
+        uint32_t pid = 0;
+        if (f) {
+            state(i, p, v, q);
+            pid = id[i];
+        }
+        // cell key + histogram of the stayers (every lane takes part in the wave-level run search)
+        uint32_t ck = 0xffffffffu;
+        if (stay)
+            ck = cell_key(G, floor_cell(q.x, G.spacing), floor_cell(q.y, G.spacing), floor_cell(q.z, G.spacing));
+        histogram_add(cell_count, ck, stay);
         if (!f) continue;
         const int t = k * (BLOCK / 64) + wave;
-        const float4 p = pos[i], v = vel[i], q = prd[i];
-        const uint32_t pid = id[i];
         if (stay) {
             const uint32_t s = block_base[0] + tile[0][t] + (uint32_t)__popcll(ms & lt);
             pos_o[s] = p;
             vel_o[s] = v;
             prd_o[s] = q;
             id_o[s] = pid;
+            key_o[s] = ck;
             if (in0) {
                 const uint32_t g = block_base[1] + tile[1][t] + (uint32_t)__popcll(m0 & lt);
                 if (g < max_records) {
@@ -1698,7 +1753,8 @@ struct pbf_ctx {
     bool owns_stream = true;
     bool uniform = false;      // every particle has uniform_mass (no per-neighbour mass gather)
     float uniform_mass = 0.f;
-    bool keyed = false;  // histogram of the live prd already accumulated by k_predict
+    bool keyed = false;  // histogram of the live prd already accumulated (k_predict / k_slab_split) ...
+    uint32_t keyed_count = 0;  // ... for the first keyed_count particles (pre-sort order)
     bool grid_valid = false;
     int32_t iterations = 1;
     std::string err;
@@ -2376,6 +2432,7 @@ int pbf_predict(pbf_ctx* c, float dt) {
         LAUNCH_CK(c);
     }
     c->keyed = !c->slab;
+    c->keyed_count = c->keyed ? c->n : 0;
     c->grid_valid = false;
     return PBF_OK;
 }
@@ -2384,9 +2441,10 @@ int pbf_build_grid(pbf_ctx* c) {
     ENTER(c);
     if (c->split_pending || c->in_exchange)
         return fail(c, PBF_ERR_INVALID, "slab exchange in flight: split_done / append_ghosts come first");
-    if (!c->keyed && c->n) {
-        k_rekey<<<nblocks(c->n), BLOCK, 0, c->stream>>>(c->prd[c->prd_cur], c->key, c->cell_count,
-                                                        c->n, make_grid(c->P));
+    const uint32_t first = c->keyed ? (c->keyed_count < c->n ? c->keyed_count : c->n) : 0u;
+    if (first < c->n) {   // particles not keyed yet (all of them, or the ones appended after a split)
+        k_rekey<<<nblocks(c->n - first), BLOCK, 0, c->stream>>>(c->prd[c->prd_cur], c->key, c->cell_count,
+                                                                c->n, make_grid(c->P), first);
         LAUNCH_CK(c);
     }
     return sort_and_neighbors(c);
@@ -2611,14 +2669,16 @@ int pbf_slab_set_bounds(pbf_ctx* c, int32_t x_lo, int32_t x_hi, int32_t ghost_la
     return PBF_OK;
 }
 
-int pbf_slab_split(pbf_ctx* c, void* d_mig_left, void* d_mig_right, void* d_ghost_left,
-                   void* d_ghost_right, uint32_t max_records, void* d_counts) {
+static int slab_split_impl(pbf_ctx* c, void* d_mig_left, void* d_mig_right, void* d_ghost_left,
+                           void* d_ghost_right, uint32_t max_records, void* d_counts, bool predict,
+                           float dt) {
     ENTER(c);
     if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
     if (c->split_pending) return fail(c, PBF_ERR_INVALID, "pbf_slab_split_done has not been called");
     if (!d_mig_left || !d_mig_right || !d_ghost_left || !d_ghost_right || !d_counts || !max_records)
         return fail(c, PBF_ERR_INVALID, "bad argument");
     HIP_CK(c, hipMemsetAsync(d_counts, 0, 6 * sizeof(uint32_t), c->stream));
+    if (c->keyed) HIP_CK(c, hipMemsetAsync(c->cell_count, 0, (size_t)c->ncell * 4, c->stream));  // stale histogram
     const int s = c->cur, d = 1 - c->cur;
     const int ps_ = c->prd_cur, pd = (c->prd_cur + 1) % 3;
     if (max_records > c->cap) max_records = c->cap;   // the boundary lists hold cap entries
@@ -2628,22 +2688,44 @@ int pbf_slab_split(pbf_ctx* c, void* d_mig_left, void* d_mig_right, void* d_ghos
         const int32_t L = c->ghost_layers;
         const int32_t lo0 = open0 ? 0 : c->x_lo, hi0 = open0 ? 0 : (int32_t)((int64_t)c->x_lo + L);
         const int32_t lo1 = open1 ? 0 : (int32_t)((int64_t)c->x_hi - L), hi1 = open1 ? 0 : c->x_hi;
-        k_slab_split<<<(c->n + SPLIT_CHUNK - 1) / SPLIT_CHUNK, BLOCK, 0, c->stream>>>(
-            c->pos[s], c->vel[s], c->prd[ps_], c->id[s], c->n, c->P.grid_spacing, c->x_lo, c->x_hi,
-            lo0, hi0, lo1, hi1, c->pos[d], c->vel[d], c->prd[pd], c->id[d], (float*)d_mig_left,
-            (float*)d_mig_right, (float*)d_ghost_left, (float*)d_ghost_right, max_records,
-            c->blist[0], c->blist[1], (uint32_t*)d_counts);
+        PredictArgs A;
+        A.dt = dt;
+        A.gx = c->P.gravity[0];
+        A.gy = c->P.gravity[1];
+        A.gz = c->P.gravity[2];
+        A.cs = c->colliders;
+        const uint32_t grid = (c->n + SPLIT_CHUNK - 1) / SPLIT_CHUNK;
+#define LAUNCH_SPLIT(PRED_)                                                                             \
+    k_slab_split<PRED_><<<grid, BLOCK, 0, c->stream>>>(                                                 \
+        c->pos[s], c->vel[s], c->prd[ps_], c->id[s], c->n, c->P.grid_spacing, c->x_lo, c->x_hi, lo0,  \
+        hi0, lo1, hi1, c->pos[d], c->vel[d], c->prd[pd], c->id[d], (float*)d_mig_left,                \
+        (float*)d_mig_right, (float*)d_ghost_left, (float*)d_ghost_right, max_records, c->blist[0],   \
+        c->blist[1], (uint32_t*)d_counts, c->key, c->cell_count, make_grid(c->P), A)
+        if (predict) {
+            PhaseScope ps(c, PH_PREDICT);
+            LAUNCH_SPLIT(true);
+        } else {
+            LAUNCH_SPLIT(false);
+        }
+#undef LAUNCH_SPLIT
         LAUNCH_CK(c);
     }
     c->cur = d;
     c->prd_cur = pd;
-    c->keyed = false;
+    c->keyed = true;       // the stayers are keyed; their number is known at pbf_slab_split_done
+    c->keyed_count = 0;
     c->grid_valid = false;
     c->split_pending = true;
     c->split_max = max_records;
     c->mig_out[0] = (const float*)d_mig_left;
     c->mig_out[1] = (const float*)d_mig_right;
     return PBF_OK;
+}
+
+int pbf_slab_split(pbf_ctx* c, void* d_mig_left, void* d_mig_right, void* d_ghost_left,
+                   void* d_ghost_right, uint32_t max_records, void* d_counts) {
+    return slab_split_impl(c, d_mig_left, d_mig_right, d_ghost_left, d_ghost_right, max_records,
+                           d_counts, false, 0.f);
 }
 
 int pbf_slab_split_done(pbf_ctx* c, const uint32_t counts[6]) {
@@ -2663,6 +2745,7 @@ int pbf_slab_split_done(pbf_ctx* c, const uint32_t counts[6]) {
     if (counts[SPLIT_GHOST_LEFT] > c->split_max || counts[SPLIT_GHOST_RIGHT] > c->split_max)
         return fail(c, PBF_ERR_CAPACITY, "ghost buffer too small");
     c->n = counts[SPLIT_STAY];
+    c->keyed_count = c->n;
     c->bcount[0] = counts[SPLIT_GHOST_LEFT];
     c->bcount[1] = counts[SPLIT_GHOST_RIGHT];
     c->mig_out_count[0] = counts[SPLIT_MIG_LEFT];
@@ -2825,7 +2908,10 @@ int pbf_slab_attach(pbf_ctx* c, pbf_comm* comm, int32_t left_rank, int32_t right
         L_CK(dalloc(&c->x_hrecv[k], (size_t)max_records));
     }
     L_CK(dalloc(&c->x_counts, (size_t)12));
-    L_CK(hipMemset(c->x_counts, 0, 12 * sizeof(uint32_t)));   // open ends stay 0 for good
+    // on the ctx stream and waited for: a null-stream memset is not ordered with the (non-blocking)
+    // ctx stream and may land after the first split has written its counters
+    L_CK(hipMemsetAsync(c->x_counts, 0, 12 * sizeof(uint32_t), c->stream));   // open ends stay 0 for good
+    L_CK(hipStreamSynchronize(c->stream));
     L_CK(hipHostMalloc((void**)&c->x_host_counts, 12 * sizeof(uint32_t), hipHostMallocDefault));
 #undef L_CK
     c->link_comm = comm;
@@ -2843,9 +2929,9 @@ int pbf_slab_step(pbf_ctx* c, float dt) {
     if (!c->link_comm) return fail(c, PBF_ERR_INVALID, "pbf_slab_attach has not been called");
     pbf_comm* comm = c->link_comm;
     const int32_t L = c->link_left, R = c->link_right;
-    int rc = pbf_predict(c, dt);
+    // predict + collide + split + key/histogram of the stayers in ONE pass over the slab
+    int rc = slab_split_impl(c, c->x_mig[0], c->x_mig[1], c->x_gh[0], c->x_gh[1], c->link_max, c->x_counts, true, dt);
     if (rc) return rc;
-    if ((rc = pbf_slab_split(c, c->x_mig[0], c->x_mig[1], c->x_gh[0], c->x_gh[1], c->link_max, c->x_counts))) return rc;
     // counts to the neighbours device-to-device, then the ONE read-back of the sub-step
     {
         uint32_t* d = c->x_counts;
@@ -3038,13 +3124,16 @@ int pbf_set_distance_constraints(pbf_ctx* c, const pbf_distance_constraint* list
     C_CK(dalloc(&c->cons_lambda, (size_t)count));
     C_CK(dalloc(&c->cons_level_start, (size_t)n_levels + 1));
     C_CK(dalloc(&c->slot_by_id, (size_t)c->cap));
-    C_CK(hipMemcpy(c->cons_p0, p0.data(), (size_t)count * 4, hipMemcpyHostToDevice));
-    C_CK(hipMemcpy(c->cons_p1, p1.data(), (size_t)count * 4, hipMemcpyHostToDevice));
-    C_CK(hipMemcpy(c->cons_rest, rest.data(), (size_t)count * 4, hipMemcpyHostToDevice));
-    C_CK(hipMemcpy(c->cons_stiff, stiff.data(), (size_t)count * 4, hipMemcpyHostToDevice));
-    C_CK(hipMemcpy(c->cons_compl, compl_.data(), (size_t)count * 4, hipMemcpyHostToDevice));
-    C_CK(hipMemcpy(c->cons_level_start, start.data(), ((size_t)n_levels + 1) * 4, hipMemcpyHostToDevice));
-    C_CK(hipMemset(c->cons_lambda, 0, (size_t)count * 4));
+    // everything on the ctx stream, then waited for (the host vectors die at return; null-stream
+    // copies / memsets are not ordered with the non-blocking ctx stream)
+    C_CK(hipMemcpyAsync(c->cons_p0, p0.data(), (size_t)count * 4, hipMemcpyHostToDevice, c->stream));
+    C_CK(hipMemcpyAsync(c->cons_p1, p1.data(), (size_t)count * 4, hipMemcpyHostToDevice, c->stream));
+    C_CK(hipMemcpyAsync(c->cons_rest, rest.data(), (size_t)count * 4, hipMemcpyHostToDevice, c->stream));
+    C_CK(hipMemcpyAsync(c->cons_stiff, stiff.data(), (size_t)count * 4, hipMemcpyHostToDevice, c->stream));
+    C_CK(hipMemcpyAsync(c->cons_compl, compl_.data(), (size_t)count * 4, hipMemcpyHostToDevice, c->stream));
+    C_CK(hipMemcpyAsync(c->cons_level_start, start.data(), ((size_t)n_levels + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    C_CK(hipMemsetAsync(c->cons_lambda, 0, (size_t)count * 4, c->stream));
+    C_CK(hipStreamSynchronize(c->stream));
 #undef C_CK
     c->cons_order = order;
     c->ncons = count;

@@ -139,7 +139,7 @@ if __name__ == "__main__":
     g.sync(); print(f"single ctx: {(time.perf_counter()-t0)/50*1e3:.3f} ms/step", flush=True)
     del g
     run_native_open(2)
-    for tr in transports:
+    for tr in [t for t in transports if t in ("torch", "rccl")]:
         for L in [int(a) for a in args] or [2]:
             run(L, tr)
     dist.destroy_process_group()

@@ -67,7 +67,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--block", type=int, nargs=3, default=None, help="nx ny nz of the particle block")
     ap.add_argument("--iters", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle sub-steps to time (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=40,
+                    help="oracle sub-steps to time on the same block as the GPU (about 10 s of CPU work; 0 = skip)")
     ap.add_argument("--cpu-block", type=int, nargs=3, default=None)
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--ghost-layers", type=int, default=4)
@@ -221,7 +222,7 @@ def main():
         value = n_total * a.steps / elapsed
         cpu = None
         if a.cpu_steps > 0 and world == 1:
-            cb = tuple(a.cpu_block) if a.cpu_block else (min(block[0], 60), min(block[1], 60), min(block[2], 60))
+            cb = tuple(a.cpu_block) if a.cpu_block else block
             cpu = cpu_baseline(cb, a.iters, a.cpu_steps)
         out = {
             "metric": "particle-substeps/sec (PBF, 4 iters)",

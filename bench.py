@@ -93,10 +93,21 @@ def cpu_baseline(block, iters, steps):
         o.step(DT)
     dt = time.perf_counter() - t0
     n = pos.shape[0]
+    # the reference hard-codes num_threads(8) in every pragma (Simulation.cpp:587,619,648,685):
+    # a shorter second sample at that setting
+    ref8 = None
+    if threads > 8:
+        o.set_threads(8)
+        k8 = max(1, steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(k8):
+            o.step(DT)
+        ref8 = n * k8 / (time.perf_counter() - t0)
     return {
         "value": n * steps / dt,
         "unit": "particle-substeps/s",
         "cores": threads,
+        "value_at_8_threads": ref8,
         "kind": "port",
         "sample": f"{steps} sub-steps of the {block[0]}x{block[1]}x{block[2]} dam-break block "
                   f"({n} particles, {iters} iterations) after 1 warm-up, CPU oracle (oracle/pbf_oracle.c) "

@@ -153,6 +153,9 @@ class Oracle:
         self.lib.orc_set_threads(self._h, threads)
         self.n = 0
 
+    def set_threads(self, threads: int):
+        self.lib.orc_set_threads(self._h, int(threads))
+
     def close(self):
         if getattr(self, "_h", None) and self._h:
             self.lib.orc_destroy(self._h)

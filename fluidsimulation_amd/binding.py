@@ -201,6 +201,7 @@ SYMBOLS = [
     "pbf_comm_last_error", "pbf_comm_batch", "pbf_slab_halo_exchange", "pbf_step_dem",
     "pbf_set_distance_constraints", "pbf_project_constraints", "pbf_get_constraint_lambdas",
     "pbf_comm_local_id", "pbf_slab_attach", "pbf_slab_step", "pbf_slab_owned_count",
+    "pbf_slab_append_owned_host", "pbf_slab_export_host",
 ]
 
 _lib = None

@@ -3003,6 +3003,39 @@ int pbf_slab_step(pbf_ctx* c, float dt) {
     return PBF_OK;
 }
 
+// host-pointer variants for callers without a device allocator of their own (the C++ driver)
+int pbf_slab_append_owned_host(pbf_ctx* c, const float* records, uint32_t count) {
+    ENTER(c);
+    if (!count) return PBF_OK;
+    if (!records) return fail(c, PBF_ERR_INVALID, "null records");
+    float* d = nullptr;
+    HIP_CK(c, dalloc(&d, (size_t)count * PBF_RECORD_FLOATS));
+    hipError_t e = hipMemcpyAsync(d, records, (size_t)count * PBF_RECORD_FLOATS * sizeof(float),
+                                  hipMemcpyHostToDevice, c->stream);
+    int rc = PBF_OK;
+    if (e != hipSuccess) rc = fail(c, PBF_ERR_HIP, std::string("append_owned_host: ") + hipGetErrorString(e));
+    if (rc == PBF_OK) rc = pbf_slab_append_owned(c, d, count, nullptr, 0);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+int pbf_slab_export_host(pbf_ctx* c, float* records, uint32_t max_records, uint32_t* count) {
+    ENTER(c);
+    if (!count || (max_records && !records)) return fail(c, PBF_ERR_INVALID, "null output");
+    float* d = nullptr;
+    HIP_CK(c, dalloc(&d, (size_t)max_records * PBF_RECORD_FLOATS));
+    int rc = pbf_slab_export(c, d, max_records, count);
+    if (rc == PBF_OK && *count) {
+        hipError_t e = hipMemcpyAsync(records, d, (size_t)*count * PBF_RECORD_FLOATS * sizeof(float),
+                                      hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, PBF_ERR_HIP, std::string("export_host: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 uint32_t pbf_slab_owned_count(const pbf_ctx* c) {
     return c ? c->n - c->ghost_count[0] - c->ghost_count[1] : 0;
 }

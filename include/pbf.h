@@ -368,6 +368,10 @@ int pbf_slab_halo_exchange(pbf_ctx* ctx, pbf_comm* comm, int32_t what, int32_t l
                            int32_t right_rank, void* d_send_left, void* d_send_right,
                            void* d_recv_left, void* d_recv_right);
 
+/* host-pointer variants of pbf_slab_append_owned / pbf_slab_export (staged through device memory
+ * by the library; synchronise) for callers that hold no device allocator, e.g. the C++ driver */
+int pbf_slab_append_owned_host(pbf_ctx* ctx, const float* records, uint32_t count);
+int pbf_slab_export_host(pbf_ctx* ctx, float* records, uint32_t max_records, uint32_t* count);
 /* the native slab runtime: attach a communicator and the neighbour ranks (< 0 = open end) to a
  * slab ctx -- the ctx allocates its exchange buffers (max_records particles per message; 0 =
  * capacity / 4) -- then pbf_slab_step runs one whole sub-step of the slab INCLUDING the

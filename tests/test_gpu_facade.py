@@ -84,3 +84,18 @@ def test_headless_driver_c2_scene_with_boundary_particles(tmp_path):
         o.step(0.0005)
     op, ov, _, _ = o.download()
     assert np.array_equal(pos, op) and np.array_equal(vel, ov)
+
+
+SLAB_RUN = ROOT / "fluidsimulation_amd" / "host" / "pbf_slab_run"
+
+
+@pytest.mark.parametrize("slabs,layers", [(2, 2), (3, 4)])
+def test_cpp_slab_driver_equals_one_ctx(slabs, layers):
+    """the multi-slab driver in plain C++ (host/pbf_slab_run.cpp + SlabDriver.h over
+    pbf_slab_attach / pbf_slab_step): rank threads over the loopback transport on this one GPU,
+    --check compares with ONE ctx stepping the whole scene, bit for bit"""
+    assert SLAB_RUN.exists(), "pbf_slab_run not built: run __graft_entry__.build()"
+    r = subprocess.run([str(SLAB_RUN), "--dims", "60", "10", "8", "--steps", "6", "--iters", "4", "--slabs", str(slabs),
+                        "--ghost-layers", str(layers), "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 of 4800 particles differ" in r.stdout

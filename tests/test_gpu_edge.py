@@ -1,0 +1,108 @@
+"""GPU edge cases of the grid / sort / neighbour build (bit-exact bar: cell indices, sorted order,
+neighbour lists) against the CPU oracle: negative and large coordinates, particles exactly on cell
+faces, ragged sizes around the workgroup / wave / scan-tile boundaries, one crowded cell, empty
+regions, duplicated positions."""
+import numpy as np
+import pytest
+
+from fluidsimulation_amd import PbfContext, PbfError
+from fluidsimulation_amd import binding as B
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+DT = 0.0005
+
+
+def params(n, dims=(16, 16, 16), origin=(0, 0, 0), h=1.0, spacing=1.0, k=64):
+    p = B.default_params()
+    p.capacity = max(n, 1)
+    p.max_neighbors = k
+    p.grid_dim[:] = list(dims)
+    p.grid_origin_cell[:] = list(origin)
+    p.effective_radius, p.grid_spacing = h, spacing
+    p.gravity[:] = [0, 0, 0]
+    return p
+
+
+def check_grid(p, pos):
+    g, o = PbfContext(p, device=0), pyoracle.Oracle(p)
+    for s in (g, o):
+        s.upload(pos, uniform_mass=0.1)
+    g.build_grid()
+    o.spatial_search()
+    xyz, key, sid, start = g.cells()
+    oxyz, _ = o.cells()
+    assert np.array_equal(xyz, oxyz)
+    gd = np.array(list(p.grid_dim), np.int64)
+    w = np.mod(oxyz.astype(np.int64) - np.array(list(p.grid_origin_cell), np.int64), gd)
+    okey = ((w[:, 0] * gd[1] + w[:, 1]) * gd[2] + w[:, 2]).astype(np.uint32)
+    assert np.array_equal(key, okey)
+    assert np.array_equal(sid, np.argsort(okey, kind="stable").astype(np.uint32))
+    occ = np.bincount(okey, minlength=start.size - 1)
+    assert np.array_equal(start, np.concatenate([[0], np.cumsum(occ)]).astype(np.uint32))
+    gc, gn = g.neighbors()
+    oc, on = o.neighbors(stride=int(p.max_neighbors))
+    assert np.array_equal(gc, oc)
+    return g, o, gc, gn, oc, on
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 5000])
+def test_ragged_sizes_around_wave_block_and_tile_boundaries(n):
+    rng = np.random.default_rng(n)
+    pos = rng.uniform(0.0, 9.0, (n, 3)).astype(np.float32)
+    g, o, gc, gn, oc, on = check_grid(params(n), pos)
+    assert np.array_equal(gn, on)          # no aliasing here: the order is the reference's too
+
+
+def test_negative_and_large_coordinates_wrap_the_grid():
+    rng = np.random.default_rng(2)
+    pos = np.concatenate([rng.uniform(-40.0, -31.0, (700, 3)), rng.uniform(1000.0, 1008.0, (700, 3)),
+                          rng.uniform(-3.0, 3.0, (700, 3))]).astype(np.float32)
+    p = params(pos.shape[0], dims=(5, 7, 6), origin=(-2, 3, 1))
+    g, o, gc, gn, oc, on = check_grid(p, pos)
+    for i in range(pos.shape[0]):          # aliased cells may reorder a row: compare as sets
+        assert sorted(gn[i, :gc[i]]) == sorted(on[i, :oc[i]])
+
+
+def test_particles_exactly_on_cell_faces_and_at_distance_h():
+    """floor() on exact multiples of the spacing, and dist2 == h*h is a neighbour (<=, inclusive,
+    NeighborSearch.cpp:219)"""
+    ax = np.arange(-3, 4, dtype=np.float32)
+    pos = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)   # spacing exactly h
+    g, o, gc, gn, oc, on = check_grid(params(pos.shape[0], origin=(-5, -5, -5)), pos)
+    assert np.array_equal(gn, on)
+    centre = int(np.where((pos == 0).all(axis=1))[0][0])
+    assert gc[centre] == 6                 # the six face neighbours at distance exactly h
+
+
+def test_duplicated_positions_and_one_crowded_cell():
+    rng = np.random.default_rng(4)
+    base = rng.uniform(2.0, 2.9, (40, 3)).astype(np.float32)      # all in one cell, all within h
+    pos = np.concatenate([base, base[:10]])                         # ten exact duplicates
+    g, o, gc, gn, oc, on = check_grid(params(pos.shape[0], k=64), pos)
+    assert np.array_equal(gn, on) and gc.min() >= 39
+    # a whole step on coincident particles must agree too (0/0 paths included)
+    g.step(DT); o.step(DT)
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op, equal_nan=True) and np.array_equal(gv, ov, equal_nan=True)
+
+
+def test_crowded_cell_beyond_the_table_is_reported():
+    rng = np.random.default_rng(5)
+    pos = rng.uniform(2.0, 2.5, (300, 3)).astype(np.float32)
+    g = PbfContext(params(300, k=32), device=0)
+    g.upload(pos, uniform_mass=0.1)
+    g.build_grid()
+    with pytest.raises(PbfError) as e:
+        g.sync()
+    assert e.value.code == B.PBF_ERR_NEIGHBOR_OVERFLOW and "299" in str(e.value)
+
+
+def test_sparse_particles_across_a_large_grid():
+    """few particles, many cells (the scan dominates; every tile path incl. > FOLD_MAX_TILES)"""
+    rng = np.random.default_rng(6)
+    pos = rng.uniform(0.0, 200.0, (3000, 3)).astype(np.float32)
+    p = params(3000, dims=(208, 208, 208))        # 9 M cells = 4394 scan tiles
+    g, o, gc, gn, oc, on = check_grid(p, pos)
+    assert np.array_equal(gn, on)

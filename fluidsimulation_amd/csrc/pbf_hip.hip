@@ -2276,7 +2276,6 @@ int pbf_set_gravity(pbf_ctx* c, float gx, float gy, float gz) {
 int pbf_set_boundary(pbf_ctx* c, const float* pos, const float* mass, float uniform_mass,
                      uint32_t nb, uint32_t max_boundary_neighbors) {
     ENTER(c);
-    if (c->slab) return fail(c, PBF_ERR_INVALID, "boundary particles are not supported in slab mode yet");
     if (nb && !pos) return fail(c, PBF_ERR_INVALID, "pos is null");
     if (nb && !mass && !(uniform_mass > 0.f)) return fail(c, PBF_ERR_INVALID, "uniform_mass must be > 0");
     if (max_boundary_neighbors > 1024) return fail(c, PBF_ERR_INVALID, "max_boundary_neighbors out of range");
@@ -2660,7 +2659,6 @@ int pbf_slab_set_bounds(pbf_ctx* c, int32_t x_lo, int32_t x_hi, int32_t ghost_la
     if (ghost_layers < 1 || ghost_layers > 8) return fail(c, PBF_ERR_INVALID, "ghost_layers must be in [1, 8]");
     if (c->P.rest_density_mode != PBF_RHO0_FIXED)
         return fail(c, PBF_ERR_INVALID, "slab mode needs PBF_RHO0_FIXED (the first-frame mean is a serial global sum)");
-    if (c->nb) return fail(c, PBF_ERR_INVALID, "boundary particles are not supported in slab mode yet");
     if (c->ncons) return fail(c, PBF_ERR_INVALID, "constraints are not available in slab mode");
     c->slab = true;
     c->x_lo = x_lo;

@@ -229,7 +229,8 @@ int pbf_snapshot_load(pbf_ctx* ctx, const char* path);
  * against this repo's oracle only).  pos: nb x 3 floats, mass: nb floats or NULL =
  * uniform_mass.  The set is static and survives pbf_upload; nb = 0 removes it.
  * max_boundary_neighbors = rows of the three boundary tables (0 = max_neighbors).  Allocates;
- * synchronises.  Not available in slab mode. */
+ * synchronises.  In slab mode every rank sets the wall particles within reach of its slab and
+ * ghost planes (the whole set is fine: volumes need each wall particle's wall neighbours). */
 int pbf_set_boundary(pbf_ctx* ctx, const float* pos, const float* mass, float uniform_mass,
                      uint32_t nb, uint32_t max_boundary_neighbors);
 uint32_t pbf_num_boundary_particles(const pbf_ctx* ctx);

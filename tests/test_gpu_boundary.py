@@ -141,16 +141,14 @@ def test_removing_the_boundary_restores_the_plain_path():
     assert same_state(g, o)
 
 
-def test_boundary_table_overflow_is_loud_and_slab_mode_refuses():
+def test_boundary_table_overflow_is_loud():
     p, pos, mass, cols, bpos, bm = scenes.boundary_tank(8, 8, 8, iterations=2)
     g = PbfContext(p, device=0)
     g.upload(pos, uniform_mass=mass)
     with pytest.raises(PbfError) as e:
         g.set_boundary(bpos, uniform_mass=bm, max_boundary_neighbors=2)
     assert e.value.code == B.PBF_ERR_NEIGHBOR_OVERFLOW
-    g.set_boundary(bpos, uniform_mass=bm)
-    with pytest.raises(PbfError):
-        g.slab_set_bounds(0, 4, 2)
+    g.set_boundary(bpos, uniform_mass=bm)     # the default table width fits
 
 
 def test_hip_reproduces_boundary_golden():

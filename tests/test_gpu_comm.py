@@ -248,3 +248,57 @@ def test_slab_simulation_bootstraps_the_native_path_on_an_nccl_group():
         sim.close()
     finally:
         dist.destroy_process_group()
+
+
+def _native_rank_with_walls(rank, world, uid, p, pos, mass, bpos, bm, planes, layers, steps, out, errs):
+    try:
+        import torch
+        from fluidsimulation_amd import slab as S
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            q = S.rank_local_params(p, pos, planes, rank, world, headroom=3.0, ghost_layers=layers)
+            b = S.HipSlabBackend(q, [], mass, planes[rank], planes[rank + 1], device=0, ghost_layers=layers)
+            b.ctx.set_boundary(bpos, uniform_mass=bm)      # every rank holds the whole (static) wall set
+            S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
+                       p.grid_spacing)
+            comm = RcclComm(uid, rank, world, 0)
+            b.ctx.slab_attach(comm, -1 if rank == 0 else rank - 1, -1 if rank == world - 1 else rank + 1,
+                              b.max_records)
+            for _ in range(steps):
+                b.ctx.slab_step(DT)
+            b.sync()
+            out[rank] = b.export()
+    except Exception as e:  # noqa: BLE001
+        errs.append((rank, repr(e)))
+
+
+@pytest.mark.parametrize("world,layers", [(2, 2), (3, 4)])
+def test_native_slabs_with_boundary_particle_walls(world, layers):
+    """8(f) rank 1 under the slab decomposition: every rank holds the static wall set; the fluid
+    is held by the particle walls only (no planes, no clamp); equal to the single-domain oracle"""
+    import threading
+    from fluidsimulation_amd import slab as S
+    from oracle import pyoracle
+    p, pos, mass, cols, bpos, bm = scenes.boundary_tank(56, 8, 6, iterations=4, tank_x_factor=1.3)
+    assert cols == []
+    steps = 12
+    planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    uid = RcclComm.local_id()
+    out, errs = {}, []
+    ts = [threading.Thread(target=_native_rank_with_walls, args=(r, world, uid, p, pos, mass, bpos, bm, planes,
+                                                                layers, steps, out, errs)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs
+    rec = np.concatenate([out[r] for r in range(world)], axis=0)
+    order = np.argsort(S.record_ids(rec))
+    o = pyoracle.Oracle(p)
+    o.upload(pos, uniform_mass=mass)
+    o.set_boundary(bpos, uniform_mass=bm)
+    for _ in range(steps):
+        o.step(DT)
+    op, ov, _, _ = o.download()
+    assert rec.shape[0] == pos.shape[0]
+    assert np.array_equal(rec[order, 0:3], op) and np.array_equal(rec[order, 4:7], ov)

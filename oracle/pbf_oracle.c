@@ -1261,8 +1261,9 @@ int orc_step_dem(orc_ctx* c, float dt, const pbf_dem_params* dem) {
  * Simulation::ProjectConstraints -> ConstraintSolver::SolveConstraints (Simulation.cpp:775-780,
  * ConstraintSolver.cpp:12-72) over DistanceConstraint (Constraints.cpp:61-120), operating on
  * m_new_positions.  (The reference's Constraint holds legacy Particle objects; here the two
- * particles are indices into the ParticleSet.)  Constraints.cpp cannot be compiled in this
- * image (Particle.h pulls in cuda_runtime.h), so this is pinned by the source text only. */
+ * particles are indices into the ParticleSet.)  Pinned by the reference itself: Constraints.cpp
+ * and ConstraintSolver.cpp are compiled into oracle/_ref (oracle/Makefile) and
+ * tests/test_oracle.py::test_constraint_solver_equals_compiled_reference compares bit for bit. */
 #define CONSTRAINT_EPSILON 0.000000000000001f /* Constraints.cpp:5 */
 
 int orc_set_distance_constraints(orc_ctx* c, const pbf_distance_constraint* list, uint32_t count, int32_t mode) {

@@ -126,6 +126,18 @@ def load_ref():
     lib.ref_glm_dot.restype = C.c_float
     lib.ref_glm_pow.argtypes = [C.c_double, C.c_int]
     lib.ref_glm_pow.restype = C.c_double
+    # Particle.cpp / Constraints.cpp / ConstraintSolver.cpp doors (present when the image held
+    # cuda_runtime.h at build time; ref_has_particles() says which build this is)
+    lib.ref_has_particles.restype = C.c_int
+    if lib.ref_has_particles():
+        u32p, i32p = C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+        lib.ref_particleset_collide.argtypes = [C.c_uint32, f3, f3, f3, f3, C.c_float, C.c_uint32, i32p, f3, f3, f3]
+        lib.ref_particleset_collide.restype = C.c_int
+        lib.ref_particleset_update.argtypes = [C.c_uint32, f3, f3, f3, C.c_float]
+        lib.ref_particleset_update.restype = None
+        lib.ref_solve_distance_constraints.argtypes = [C.c_int32, C.c_float, C.c_uint32, C.c_uint32, f3, f3,
+                                                       C.c_uint32, u32p, u32p, f3, f3, f3, f3]
+        lib.ref_solve_distance_constraints.restype = C.c_int
     _ref = lib
     return lib
 

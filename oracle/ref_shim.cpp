@@ -2,13 +2,26 @@
 //
 // extern "C" doors into the reference's OWN sources, compiled where they lie under
 // /root/reference (never copied): SPHKernel.h (header-only), CollisionDetection.cpp and
-// Collider.cpp.  These are the only pieces of the reference's CPU path that build with
-// this image's toolchain without stand-ins: Particle.cpp / NeighborSearch.cpp /
-// Simulation.cpp need cuda_runtime.h, GL and ImGui headers the image lacks (treated as
-// unbuildable).  The only accommodation is -D__forceinline=inline for the
-// MSVC keyword at Collider.h:26.  Output goes to oracle/_ref/ (git-ignored).
+// Collider.cpp; and, when the image holds NVIDIA's own cuda_runtime.h (it ships inside the
+// installed triton wheel; Particle.h:7 includes it for the float3 type) also Particle.cpp,
+// Constraints.cpp and ConstraintSolver.cpp (-DREF_WITH_PARTICLES, see oracle/Makefile).
+// Every symbol these objects reference is defined by them, libstdc++ or libm: nothing is
+// stubbed.  NeighborSearch.cpp / ParticleSystem.cpp / Simulation.cpp stay out: they call into
+// libcudart and GLEW, which the image lacks (treated as unbuildable), and use
+// MSVC-only library names (std::floorf, steady_clock = high_resolution_clock).  The only
+// accommodation is -D__forceinline=inline for the MSVC keyword at Collider.h:26.  Output goes
+// to oracle/_ref/ (git-ignored).
+#include <cstdint>
+#include <memory>
+#include <vector>
+
 #include "SPHKernel.h"
 #include "CollisionDetection.h"
+#ifdef REF_WITH_PARTICLES
+#include "Particle.h"
+#include "Constraints.h"
+#include "ConstraintSolver.h"
+#endif
 
 extern "C" {
 
@@ -46,5 +59,98 @@ float ref_glm_dot(const float* a, const float* b) {
 }
 
 double ref_glm_pow(double x, int e) { return glm::pow(x, e); }
+
+#ifdef REF_WITH_PARTICLES
+int ref_has_particles(void) { return 1; }
+
+static Collider* make_collider(int32_t type, const float* a, const float* b, float d) {
+    if (type == (int32_t)Collider::ColliderTypes::PLANE) return new PlaneCollider(glm::vec3(a[0], a[1], a[2]), d);
+    if (type == (int32_t)Collider::ColliderTypes::AABB)
+        return new AABB(glm::vec3(a[0], a[1], a[2]), glm::vec3(b[0], b[1], b[2]));
+    return nullptr;
+}
+
+// The particle loop of Simulation::CollisionDetection (Simulation.cpp:731-739) over the
+// reference's ParticleSet::TestCollision / OnCollision (Particle.cpp:217-338).
+// type/a/b/d: ncol colliders (a, b: 3 floats each).  vel, pred, newp are updated in place.
+int ref_particleset_collide(uint32_t n, const float* pos, float* vel, float* pred, float* newp, float dt,
+                            uint32_t ncol, const int32_t* type, const float* a, const float* b, const float* d) {
+    ParticleSet set(n, 1.0f);
+    for (uint32_t i = 0; i < n; ++i) {
+        set.m_positions[i] = glm::vec3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+        set.m_velocity[i] = glm::vec3(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2]);
+        set.m_predict_positions[i] = glm::vec3(pred[3 * i], pred[3 * i + 1], pred[3 * i + 2]);
+        set.m_new_positions[i] = glm::vec3(newp[3 * i], newp[3 * i + 1], newp[3 * i + 2]);
+    }
+    std::vector<Collider*> cols;
+    for (uint32_t j = 0; j < ncol; ++j) {
+        Collider* c = make_collider(type[j], a + 3 * j, b + 3 * j, d[j]);
+        if (!c) return 1;
+        cols.push_back(c);
+    }
+    for (size_t i = 0; i < set.m_size; ++i)
+        for (size_t j = 0; j < cols.size(); ++j)
+            if (set.TestCollision(i, cols[j])) set.OnCollision(i, cols[j], dt);
+    for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            vel[3 * i + k] = set.m_velocity[i][k];
+            pred[3 * i + k] = set.m_predict_positions[i][k];
+            newp[3 * i + k] = set.m_new_positions[i][k];
+        }
+    for (Collider* c : cols) delete c;
+    return 0;
+}
+
+// ParticleSet::Update (Particle.cpp:207-215): v = (new - p) / dt, p = new
+void ref_particleset_update(uint32_t n, float* pos, float* vel, const float* newp, float dt) {
+    ParticleSet set(n, 1.0f);
+    for (uint32_t i = 0; i < n; ++i) {
+        set.m_positions[i] = glm::vec3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+        set.m_new_positions[i] = glm::vec3(newp[3 * i], newp[3 * i + 1], newp[3 * i + 2]);
+    }
+    set.Update(dt);
+    for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            pos[3 * i + k] = set.m_positions[i][k];
+            vel[3 * i + k] = set.m_velocity[i][k];
+        }
+}
+
+// ConstraintSolver::SolveConstraints (ConstraintSolver.cpp:12-72) over DistanceConstraint
+// objects (Constraints.cpp:50-120) holding the reference's Particle objects.
+// mode: 0 = PBD_MODE::PBD, 1 = PBD_MODE::XPBD.  newp (n x 3) is updated in place; lambdas (k) out.
+int ref_solve_distance_constraints(int32_t mode, float dt, uint32_t iterations, uint32_t n, float* newp,
+                                   const float* mass, uint32_t k, const uint32_t* p0, const uint32_t* p1,
+                                   const float* rest, const float* stiffness, const float* compliance,
+                                   float* lambdas) {
+    std::vector<Particle_Ptr> parts;
+    for (uint32_t i = 0; i < n; ++i) {
+        const glm::vec3 x(newp[3 * i], newp[3 * i + 1], newp[3 * i + 2]);
+        Particle_Ptr p = std::make_shared<Particle>(x, mass[i]);
+        p->m_new_position = x;
+        parts.push_back(p);
+    }
+    std::vector<Constraint*> list, none;
+    for (uint32_t c = 0; c < k; ++c) {
+        if (p0[c] >= n || p1[c] >= n) return 1;
+        DistanceConstraint* dc = new DistanceConstraint(parts[p0[c]], parts[p1[c]], rest[c]);
+        dc->setStiffness(stiffness[c]);
+        dc->setCompliance(compliance[c]);
+        list.push_back(dc);
+    }
+    ConstraintSolver solver(mode == 1 ? PBD_MODE::XPBD : PBD_MODE::PBD);
+    solver.setSolverIteration(iterations);
+    const bool ok = solver.SolveConstraints(dt, list, none);
+    for (uint32_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) newp[3 * i + c] = parts[i]->m_new_position[c];
+    for (uint32_t c = 0; c < k; ++c) {
+        lambdas[c] = list[c]->m_lambda;
+        delete static_cast<DistanceConstraint*>(list[c]);
+    }
+    return ok ? 0 : 2;
+}
+#else
+int ref_has_particles(void) { return 0; }
+#endif
 
 }  // extern "C"

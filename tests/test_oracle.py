@@ -141,6 +141,99 @@ def test_leaf_arithmetic_equals_compiled_reference(lib):
         assert ref.ref_glm_pow(float(x), 4) == float(x) ** 4.0 or abs(ref.ref_glm_pow(float(x), 4) - float(x) ** 4) <= 2e-16 * float(x) ** 4
 
 
+def _ref_with_particles():
+    ref = pyoracle.load_ref()
+    if ref is None or not ref.ref_has_particles():
+        pytest.skip("oracle/_ref was built without Particle.cpp / Constraints.cpp (no cuda_runtime.h at build time)")
+    return ref
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def test_collision_response_and_update_equal_compiled_reference():
+    """ParticleSet::TestCollision / OnCollision / Update (Particle.cpp:207-338), compiled from
+    /root/reference, driven by the particle loop of Simulation::CollisionDetection
+    (Simulation.cpp:731-739), against orc_collision_detection / orc_apply_solver_results on the
+    same random state: bit-identical velocities, predicted and new positions."""
+    ref = _ref_with_particles()
+    from fluidsimulation_amd import binding as B
+    rng = np.random.default_rng(77)
+    n = 3000
+    cols = [B.plane((0, 1, 0), 0.0), B.plane((1, 0, 0), -0.5),
+            B.aabb((0.2, 0.1, 0.2), (0.9, 0.8, 1.1)), B.plane((-1, 0, 0), -1.5)]
+    p = B.default_params()
+    p.capacity = n
+    o = pyoracle.Oracle(p)
+    pos = rng.uniform(-0.7, 1.7, (n, 3)).astype(np.float32)
+    pos[:, 1] = rng.uniform(-0.05, 1.0, n).astype(np.float32)
+    vel = rng.normal(0, 30.0, (n, 3)).astype(np.float32)
+    o.upload(pos, vel=vel, uniform_mass=1.0)
+    o.set_colliders(cols)
+    o.predict_positions(DT)
+    v0, x0 = o.get_array("vel").copy(), o.get_array("pred").copy()
+    o.collision_detection(DT)
+    _, v1, x1, new1 = o.download()
+    rv, rp, rn = v0.copy(), x0.copy(), x0.copy()
+    typ = np.array([c.type for c in cols], np.int32)
+    a = np.array([list(c.a) for c in cols], np.float32)
+    b = np.array([list(c.b) for c in cols], np.float32)
+    d = np.array([c.d for c in cols], np.float32)
+    rc = ref.ref_particleset_collide(n, _fp(pos), _fp(rv), _fp(rp), _fp(rn), DT, len(cols),
+                                     typ.ctypes.data_as(C.POINTER(C.c_int32)), _fp(a), _fp(b), _fp(d))
+    assert rc == 0
+    assert (x1 != x0).any(axis=1).sum() > n // 10          # the case does collide
+    assert rv.tobytes() == v1.tobytes()
+    assert rp.tobytes() == x1.tobytes()
+    assert rn.tobytes() == new1.tobytes()
+    # ParticleSet::Update against the oracle's velocity update
+    o.apply_solver_results(DT)
+    p2, v2, _, _ = o.download()
+    rpos, rvel = pos.copy(), np.zeros_like(pos)
+    ref.ref_particleset_update(n, _fp(rpos), _fp(rvel), _fp(new1), DT)
+    assert rpos.tobytes() == p2.tobytes() and rvel.tobytes() == v2.tobytes()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_constraint_solver_equals_compiled_reference(mode):
+    """ConstraintSolver::SolveConstraints over DistanceConstraint objects (ConstraintSolver.cpp,
+    Constraints.cpp compiled from /root/reference) against orc_project_constraints on a random
+    constraint graph with shared particles, unequal masses, several iterations: bit-identical
+    positions and XPBD multipliers."""
+    ref = _ref_with_particles()
+    from fluidsimulation_amd import binding as B
+    rng = np.random.default_rng(5 + mode)
+    n, k, iters = 400, 1500, 3
+    x = rng.uniform(0, 4, (n, 3)).astype(np.float32)
+    mass = rng.uniform(0.5, 3.0, n).astype(np.float32)
+    p0 = rng.integers(0, n, k).astype(np.uint32)
+    p1 = ((p0 + rng.integers(1, n, k)) % n).astype(np.uint32)
+    rest = rng.uniform(0.1, 2.0, k).astype(np.float32)
+    stiff = rng.uniform(-0.2, 1.3, k).astype(np.float32)       # also exercises the [0, 1] clamp
+    comp = (rng.uniform(0, 1e-6, k) * (rng.random(k) < 0.7)).astype(np.float32)
+    x[p1[0]] = x[p0[0]]                                         # a zero-length pair: the EPSILON guard
+    p = B.default_params()
+    p.capacity = n
+    p.solver_iterations = iters
+    o = pyoracle.Oracle(p)
+    o.upload(x, mass=mass)
+    o.set_array("pred", x)
+    o.set_distance_constraints([(int(p0[c]), int(p1[c]), float(rest[c]), float(stiff[c]), float(comp[c]))
+                                for c in range(k)], B.PBF_CONSTRAINTS_XPBD if mode else B.PBF_CONSTRAINTS_PBD)
+    o.project_constraints(DT)
+    got = o.download()[3]
+    rx, lam = x.copy(), np.zeros(k, np.float32)
+    u32 = C.POINTER(C.c_uint32)
+    rc = ref.ref_solve_distance_constraints(mode, DT, iters, n, _fp(rx), _fp(mass), k, p0.ctypes.data_as(u32),
+                                            p1.ctypes.data_as(u32), _fp(rest), _fp(stiff), _fp(comp), _fp(lam))
+    assert rc == 0
+    assert np.isfinite(rx).all()
+    assert rx.tobytes() == got.tobytes()
+    if mode:
+        assert lam.tobytes() == o.constraint_lambdas().tobytes()
+
+
 # ------------------------------------------------------------------ search
 
 def _jittered(nx, ny, nz, amp, seed):

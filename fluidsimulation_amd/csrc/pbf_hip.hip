@@ -58,6 +58,7 @@ const char* kPhaseNames[PH_COUNT] = {"predict", "sort",     "neighbors", "rest_d
 struct DevFlags {
     uint32_t neighbor_overflow;  // particles whose neighbour count exceeded K
     uint32_t max_count;
+    uint32_t x_wrapped;          // a particle's cell lies outside the grid in x (its key wrapped)
 };
 
 // ------------------------------------------------------------------------------------
@@ -373,6 +374,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(uint32_t* __restrict__ cou
     if (flags && blockIdx.x == 0 && threadIdx.x == 0) {
         flags->neighbor_overflow = 0u;
         flags->max_count = 0u;
+        flags->x_wrapped = 0u;
     }
     uint32_t tile_base;
     if (FOLD) {
@@ -596,7 +598,9 @@ __global__ __launch_bounds__(BLOCK) void k_neighbors(const float4* __restrict__ 
     bool interior = true;
     if (active) {
         xi = q[i];
-        const uint32_t wx = (uint32_t)wrap(floor_cell(xi.x, G.spacing) - G.ox, G.gx);
+        const int32_t ux = floor_cell(xi.x, G.spacing) - G.ox;
+        if (SELF && (ux < 0 || ux >= G.gx)) flags->x_wrapped = 1u;   // cell planes are no longer slot runs
+        const uint32_t wx = (uint32_t)wrap(ux, G.gx);
         const uint32_t wy = (uint32_t)wrap(floor_cell(xi.y, G.spacing) - G.oy, G.gy);
         const uint32_t wz = (uint32_t)wrap(floor_cell(xi.z, G.spacing) - G.oz, G.gz);
         key = (wx * (uint32_t)G.gy + wy) * (uint32_t)G.gz + wz;
@@ -739,6 +743,26 @@ __global__ void k_rest_density_mean(const float* __restrict__ dens_by_id, uint32
     *rho0 = acc;
 }
 
+// Sweep window: the sorted slots [cell_start[key_a], cell_start[key_b]) when a window is given
+// (slab mode: the owned cell planes plus as many ghost planes as the iteration still needs; the
+// grid key has x outermost, so a run of cell planes is a contiguous run of slots -- unless some
+// particle's cell wrapped around the grid in x, which k_neighbors flags), else [0, n).
+// Returns false for threads outside it.  Blocks are spread over the window XCD-aware.
+__device__ __forceinline__ bool sweep_index(const uint32_t* __restrict__ win_start, uint32_t key_a,
+                                            uint32_t key_b, const DevFlags* __restrict__ flags,
+                                            uint32_t n, uint32_t& i) {
+    uint32_t i0 = 0, cnt = n;
+    if (win_start && !flags->x_wrapped) {
+        i0 = win_start[key_a];
+        cnt = win_start[key_b] - i0;
+    }
+    const uint32_t nbk = (cnt + BLOCK - 1) / BLOCK;
+    if (blockIdx.x >= nbk) return false;
+    const uint32_t k = xcd_block(blockIdx.x, nbk) * BLOCK + threadIdx.x;
+    i = i0 + k;
+    return k < cnt;
+}
+
 // ------------------------------------------------------------------------------------
 // a13 + a14 fused: Simulation::ComputeDensity and ComputeLambdas (Simulation.cpp:607-679)
 // share one pass over the neighbour row: rho_i and sum_j |gradW/rho0|^2 are independent.
@@ -757,9 +781,12 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __r
                                                   float* __restrict__ C_out,
                                                   const float4* __restrict__ bpos,
                                                   const uint32_t* __restrict__ fb,
-                                                  const uint32_t* __restrict__ fb_count) {
-    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
-    if (i >= n) return;
+                                                  const uint32_t* __restrict__ fb_count,
+                                                  const uint32_t* __restrict__ win_start,
+                                                  uint32_t win_a, uint32_t win_b,
+                                                  const DevFlags* __restrict__ flags) {
+    uint32_t i;
+    if (!sweep_index(win_start, win_a, win_b, flags, n, i)) return;
     const float rho0 = *rho0_ptr;
     const float inv_rho0 = 1.f / rho0;
     const float4 xi = prd[i];
@@ -817,9 +844,11 @@ __global__ __launch_bounds__(BLOCK) void k_delta(const float4* __restrict__ prd,
                                                  const uint32_t* __restrict__ fb,
                                                  const uint32_t* __restrict__ fb_count,
                                                  float4* __restrict__ pos, float4* __restrict__ vel,
-                                                 float dt) {
-    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
-    if (i >= n) return;
+                                                 float dt, const uint32_t* __restrict__ win_start,
+                                                 uint32_t win_a, uint32_t win_b,
+                                                 const DevFlags* __restrict__ flags) {
+    uint32_t i;
+    if (!sweep_index(win_start, win_a, win_b, flags, n, i)) return;
     const float inv_rho0 = 1.f / *rho0_ptr;
     const float4 xi = prd[i];
     float nx = xi.x, ny = xi.y, nz = xi.z;
@@ -1324,6 +1353,15 @@ __device__ __forceinline__ void write_record(float* rec, const float4& p, const 
     r[2] = make_float4(q.x, q.y, q.z, 0.f);
 }
 
+// A ghost needs its old position and velocity only for the viscosity stages and its mass only
+// when masses differ: otherwise the record shrinks to one float4 (prd.xyz, id bits) -- a third of
+// the bytes on the link.
+__device__ __forceinline__ void write_ghost(float* buf, uint32_t g, const float4& p, const float4& v,
+                                            uint32_t id, const float4& q, int compact) {
+    if (compact) reinterpret_cast<float4*>(buf)[g] = make_float4(q.x, q.y, q.z, __uint_as_float(id));
+    else write_record(buf + 12 * (size_t)g, p, v, id, q);
+}
+
 // counter slots of the split (device memory the caller may forward to its neighbours)
 enum { SPLIT_STAY = 0, SPLIT_TOO_FAR = 1, SPLIT_MIG_LEFT = 2, SPLIT_GHOST_LEFT = 3, SPLIT_MIG_RIGHT = 4, SPLIT_GHOST_RIGHT = 5 };
 
@@ -1356,7 +1394,7 @@ __global__ __launch_bounds__(BLOCK) void k_slab_split(
     float* __restrict__ mig0, float* __restrict__ mig1, float* __restrict__ gh0,
     float* __restrict__ gh1, uint32_t max_records, uint32_t* __restrict__ blist0,
     uint32_t* __restrict__ blist1, uint32_t* __restrict__ cnt, uint32_t* __restrict__ key_o,
-    uint32_t* __restrict__ cell_count, GridConsts G, PredictArgs A) {
+    uint32_t* __restrict__ cell_count, GridConsts G, PredictArgs A, int compact_ghosts) {
     __shared__ uint32_t tile[3][SPLIT_TILES];
     __shared__ uint32_t block_base[3];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1461,14 +1499,14 @@ __global__ __launch_bounds__(BLOCK) void k_slab_split(
             if (in0) {
                 const uint32_t g = block_base[1] + tile[1][t] + (uint32_t)__popcll(m0 & lt);
                 if (g < max_records) {
-                    write_record(gh0 + 12 * (size_t)g, p, v, pid, q);
+                    write_ghost(gh0, g, p, v, pid, q, compact_ghosts);
                     blist0[g] = s;
                 }
             }
             if (in1) {
                 const uint32_t g = block_base[2] + tile[2][t] + (uint32_t)__popcll(m1 & lt);
                 if (g < max_records) {
-                    write_record(gh1 + 12 * (size_t)g, p, v, pid, q);
+                    write_ghost(gh1, g, p, v, pid, q, compact_ghosts);
                     blist1[g] = s;
                 }
             }
@@ -1495,6 +1533,23 @@ __global__ __launch_bounds__(BLOCK) void k_slab_append(const float* __restrict__
     vel[base + i] = make_float4(v.x, v.y, v.z, 0.f);
     prd[base + i] = make_float4(q.x, q.y, q.z, 0.f);
     id[base + i] = pid;
+}
+
+// compact ghost records (write_ghost): the old position is the predicted one, the velocity zero --
+// neither is read for a ghost without the viscosity stages
+__global__ __launch_bounds__(BLOCK) void k_slab_append_compact(const float4* __restrict__ rec, uint32_t count,
+                                                               uint32_t base, float mass,
+                                                               float4* __restrict__ pos,
+                                                               float4* __restrict__ vel,
+                                                               float4* __restrict__ prd,
+                                                               uint32_t* __restrict__ id) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const float4 r = rec[i];
+    pos[base + i] = make_float4(r.x, r.y, r.z, mass);
+    vel[base + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    prd[base + i] = make_float4(r.x, r.y, r.z, 0.f);
+    id[base + i] = (__float_as_uint(r.w) & ~GHOST_BIT) | GHOST_BIT;
 }
 
 // migrants that arrived from one side join that side's boundary list: blist[at + e] = base + e
@@ -2467,9 +2522,35 @@ int pbf_compute_rest_density(pbf_ctx* c) {
     return PBF_OK;
 }
 
-static int solve_half(pbf_ctx* c, int half, float dt, bool fuse_finalize = false) {
+// keys of the first cell of the plane `depth` ghost planes left of the slab and of the first plane
+// beyond `depth` ghost planes on the right (an open end: the whole side).  False when the slab's
+// ghost planes do not fit the rank-local grid unwrapped (then sweep everything).
+static bool slab_window(const pbf_ctx* c, int32_t depth, uint32_t* key_a, uint32_t* key_b) {
+    const int64_t gx = c->P.grid_dim[0], plane = (int64_t)c->P.grid_dim[1] * c->P.grid_dim[2];
+    const int64_t ox = c->P.grid_origin_cell[0], L = c->ghost_layers;
+    int64_t a = 0, b = gx;
+    if (c->x_lo != INT32_MIN) {
+        if ((int64_t)c->x_lo - L - ox < 0) return false;
+        a = (int64_t)c->x_lo - depth - ox;
+    }
+    if (c->x_hi != INT32_MAX) {
+        if ((int64_t)c->x_hi + L - ox > gx) return false;
+        b = (int64_t)c->x_hi + depth - ox;
+    }
+    if (depth > L || a < 0 || b > gx || a >= b) return false;
+    *key_a = (uint32_t)(a * plane);
+    *key_b = (uint32_t)(b * plane);
+    return true;
+}
+
+// ghost_depth >= 0 (slab mode): sweep only the owned cell planes plus that many ghost planes per
+// side (sweep_index); -1: every particle
+static int solve_half(pbf_ctx* c, int half, float dt, bool fuse_finalize = false, int32_t ghost_depth = -1) {
     const KernConsts kc = make_kern(c->P, dt);
     const uint32_t nb = nblocks(c->n);
+    const uint32_t* win_start = nullptr;
+    uint32_t win_a = 0, win_b = 0;
+    if (ghost_depth >= 0 && c->slab && slab_window(c, ghost_depth, &win_a, &win_b)) win_start = c->cell_start;
     const bool spiky = c->P.gradient_kernel == PBF_GRAD_SPIKY;
     float4* x = c->prd[c->prd_cur];
     if (half == 0) {
@@ -2477,7 +2558,8 @@ static int solve_half(pbf_ctx* c, int half, float dt, bool fuse_finalize = false
 #define LAUNCH_LAMBDA(U, G, B)                                                                \
     k_lambda<U, G, B><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count, c->n, \
                                                    c->cap, kc, c->rho0, c->uniform_mass, c->dens, \
-                                                   c->C, c->bpos, c->fb, c->fb_count)
+                                                   c->C, c->bpos, c->fb, c->fb_count, win_start,  \
+                                                   win_a, win_b, c->flags)
 #define LAUNCH_LAMBDA_UG(U, G)            \
     do {                                  \
         if (c->nb) LAUNCH_LAMBDA(U, G, true); \
@@ -2519,7 +2601,7 @@ static int solve_half(pbf_ctx* c, int half, float dt, bool fuse_finalize = false
     k_delta<G, B, F><<<nb, BLOCK, 0, c->stream>>>(x, y, c->nbr, c->nbr_count, c->n, c->cap, kc,   \
                                                   c->rho0, c->P.container_enabled, cmin, cmax,    \
                                                   c->bprd, c->fb, c->fb_count, c->pos[c->cur],    \
-                                                  c->vel[c->cur], dt)
+                                                  c->vel[c->cur], dt, win_start, win_a, win_b, c->flags)
 #define LAUNCH_DELTA_F(G, B)                  \
     do {                                      \
         if (fuse_finalize) LAUNCH_DELTA(G, B, true); \
@@ -2669,7 +2751,7 @@ int pbf_slab_set_bounds(pbf_ctx* c, int32_t x_lo, int32_t x_hi, int32_t ghost_la
 
 static int slab_split_impl(pbf_ctx* c, void* d_mig_left, void* d_mig_right, void* d_ghost_left,
                            void* d_ghost_right, uint32_t max_records, void* d_counts, bool predict,
-                           float dt) {
+                           float dt, bool compact_ghosts = false) {
     ENTER(c);
     if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
     if (c->split_pending) return fail(c, PBF_ERR_INVALID, "pbf_slab_split_done has not been called");
@@ -2698,7 +2780,8 @@ static int slab_split_impl(pbf_ctx* c, void* d_mig_left, void* d_mig_right, void
         c->pos[s], c->vel[s], c->prd[ps_], c->id[s], c->n, c->P.grid_spacing, c->x_lo, c->x_hi, lo0,  \
         hi0, lo1, hi1, c->pos[d], c->vel[d], c->prd[pd], c->id[d], (float*)d_mig_left,                \
         (float*)d_mig_right, (float*)d_ghost_left, (float*)d_ghost_right, max_records, c->blist[0],   \
-        c->blist[1], (uint32_t*)d_counts, c->key, c->cell_count, make_grid(c->P), A)
+        c->blist[1], (uint32_t*)d_counts, c->key, c->cell_count, make_grid(c->P), A,                  \
+        compact_ghosts ? 1 : 0)
         if (predict) {
             PhaseScope ps(c, PH_PREDICT);
             LAUNCH_SPLIT(true);
@@ -2752,13 +2835,18 @@ int pbf_slab_split_done(pbf_ctx* c, const uint32_t counts[6]) {
     return PBF_OK;
 }
 
-static int slab_append_one(pbf_ctx* c, const void* d_records, uint32_t count, bool ghost) {
+static int slab_append_one(pbf_ctx* c, const void* d_records, uint32_t count, bool ghost, bool compact = false) {
     if ((uint64_t)c->n + count > c->cap) return fail(c, PBF_ERR_CAPACITY, "slab exceeds ctx capacity");
     if (count) {
         if (!d_records) return fail(c, PBF_ERR_INVALID, "null records");
-        k_slab_append<<<nblocks(count), BLOCK, 0, c->stream>>>(
-            (const float*)d_records, count, c->n, ghost ? GHOST_BIT : 0u, c->pos[c->cur],
-            c->vel[c->cur], c->prd[c->prd_cur], c->id[c->cur]);
+        if (compact)
+            k_slab_append_compact<<<nblocks(count), BLOCK, 0, c->stream>>>(
+                (const float4*)d_records, count, c->n, c->uniform_mass, c->pos[c->cur], c->vel[c->cur],
+                c->prd[c->prd_cur], c->id[c->cur]);
+        else
+            k_slab_append<<<nblocks(count), BLOCK, 0, c->stream>>>(
+                (const float*)d_records, count, c->n, ghost ? GHOST_BIT : 0u, c->pos[c->cur],
+                c->vel[c->cur], c->prd[c->prd_cur], c->id[c->cur]);
         LAUNCH_CK(c);
     }
     c->n += count;
@@ -2792,8 +2880,8 @@ int pbf_slab_append_owned(pbf_ctx* c, const void* d_from_left, uint32_t count_le
     return PBF_OK;
 }
 
-int pbf_slab_append_ghosts(pbf_ctx* c, const void* d_from_left, uint32_t count_left,
-                           const void* d_from_right, uint32_t count_right) {
+static int slab_append_ghosts_impl(pbf_ctx* c, const void* d_from_left, uint32_t count_left,
+                                   const void* d_from_right, uint32_t count_right, bool compact) {
     ENTER(c);
     if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
     if (!c->in_exchange) return fail(c, PBF_ERR_INVALID, "pbf_slab_split / pbf_slab_split_done come first");
@@ -2801,7 +2889,7 @@ int pbf_slab_append_ghosts(pbf_ctx* c, const void* d_from_left, uint32_t count_l
     const uint32_t cnt[2] = {count_left, count_right};
     for (int side = 0; side < 2; ++side) {
         c->ghost_base[side] = c->n;
-        int rc = slab_append_one(c, rec[side], cnt[side], true);
+        int rc = slab_append_one(c, rec[side], cnt[side], true, compact);
         if (rc) return rc;
         // this slab's own migrants to that side stay here as ghosts (their new owner lists them
         // in the same order, right after its boundary-plane particles)
@@ -2811,6 +2899,11 @@ int pbf_slab_append_ghosts(pbf_ctx* c, const void* d_from_left, uint32_t count_l
     }
     c->in_exchange = false;
     return PBF_OK;
+}
+
+int pbf_slab_append_ghosts(pbf_ctx* c, const void* d_from_left, uint32_t count_left,
+                           const void* d_from_right, uint32_t count_right) {
+    return slab_append_ghosts_impl(c, d_from_left, count_left, d_from_right, count_right, false);
 }
 
 static float4* halo_array(pbf_ctx* c, int32_t what) {
@@ -2928,7 +3021,10 @@ int pbf_slab_step(pbf_ctx* c, float dt) {
     pbf_comm* comm = c->link_comm;
     const int32_t L = c->link_left, R = c->link_right;
     // predict + collide + split + key/histogram of the stayers in ONE pass over the slab
-    int rc = slab_split_impl(c, c->x_mig[0], c->x_mig[1], c->x_gh[0], c->x_gh[1], c->link_max, c->x_counts, true, dt);
+    // ghosts travel as one float4 each unless a later stage reads their velocity / old position
+    // (viscosity) or masses differ; every rank takes the same decision from the shared parameters
+    const bool compact = c->uniform && c->P.vorticity_eps == 0.f && c->P.xsph_c == 0.f;
+    int rc = slab_split_impl(c, c->x_mig[0], c->x_mig[1], c->x_gh[0], c->x_gh[1], c->link_max, c->x_counts, true, dt, compact);
     if (rc) return rc;
     // counts to the neighbours device-to-device, then the ONE read-back of the sub-step
     {
@@ -2948,18 +3044,18 @@ int pbf_slab_step(pbf_ctx* c, float dt) {
         from_right[1] > c->link_max)
         return fail(c, PBF_ERR_CAPACITY, "incoming migrants / ghosts exceed the exchange buffers (pbf_slab_attach max_records)");
     {
-        const uint64_t rb = PBF_RECORD_FLOATS * sizeof(float);
+        const uint64_t rb = PBF_RECORD_FLOATS * sizeof(float), gb = compact ? sizeof(float4) : rb;
         pbf_p2p ops[8] = {{1, L, c->x_mig[0], own[2] * rb}, {0, L, c->x_rmig[0], from_left[0] * rb},
-                          {1, L, c->x_gh[0], own[3] * rb},  {0, L, c->x_rgh[0], from_left[1] * rb},
+                          {1, L, c->x_gh[0], own[3] * gb},  {0, L, c->x_rgh[0], from_left[1] * gb},
                           {1, R, c->x_mig[1], own[4] * rb}, {0, R, c->x_rmig[1], from_right[0] * rb},
-                          {1, R, c->x_gh[1], own[5] * rb},  {0, R, c->x_rgh[1], from_right[1] * rb}};
+                          {1, R, c->x_gh[1], own[5] * gb},  {0, R, c->x_rgh[1], from_right[1] * gb}};
         if (L < 0) for (int k = 0; k < 4; ++k) ops[k].bytes = 0;
         if (R < 0) for (int k = 4; k < 8; ++k) ops[k].bytes = 0;
         rc = pbf_comm_batch(comm, (void*)c->stream, ops, 8);
         if (rc) return fail(c, rc, std::string("payload exchange: ") + pbf_comm_last_error(comm));
     }
     if ((rc = pbf_slab_append_owned(c, c->x_rmig[0], L < 0 ? 0 : from_left[0], c->x_rmig[1], R < 0 ? 0 : from_right[0]))) return rc;
-    if ((rc = pbf_slab_append_ghosts(c, c->x_rgh[0], L < 0 ? 0 : from_left[1], c->x_rgh[1], R < 0 ? 0 : from_right[1]))) return rc;
+    if ((rc = slab_append_ghosts_impl(c, c->x_rgh[0], L < 0 ? 0 : from_left[1], c->x_rgh[1], R < 0 ? 0 : from_right[1], compact))) return rc;
     if (c->bcount[0] > c->link_max || c->bcount[1] > c->link_max || c->ghost_count[0] > c->link_max ||
         c->ghost_count[1] > c->link_max)
         return fail(c, PBF_ERR_CAPACITY, "halo exceeds the exchange buffers (pbf_slab_attach max_records)");
@@ -2977,14 +3073,14 @@ int pbf_slab_step(pbf_ctx* c, float dt) {
             if ((rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
             valid = layers;
         }
-        if ((rc = pbf_solve_lambda(c, dt))) return rc;
-        if (!local_sweeps && (rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
+        // what the sweeps of this iteration still have to produce: lambda on valid - 1 ghost planes,
+        // delta-p on valid - 2 (the last iteration: only what the owned particles need)
         const bool last = it + 1 == c->iterations;
-        if (last && fused) {
-            if (c->n && (rc = solve_half(c, 1, dt, true))) return rc;
-        } else if ((rc = pbf_solve_delta(c, dt))) {
-            return rc;
-        }
+        const int32_t depth_l = !local_sweeps ? -1 : (last ? 1 : valid - 1);
+        const int32_t depth_d = !local_sweeps ? -1 : (last ? 0 : valid - 2);
+        if (c->n && (rc = solve_half(c, 0, dt, false, depth_l))) return rc;
+        if (!local_sweeps && (rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
+        if (c->n && (rc = solve_half(c, 1, dt, last && fused, depth_d))) return rc;
         if (local_sweeps) valid -= 2;
         else if (!last && (rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
     }

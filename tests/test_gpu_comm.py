@@ -162,6 +162,68 @@ def test_native_slab_step_over_loopback_equals_single_domain(world, layers, visc
     assert all(out[r].shape[0] > 0 for r in range(world))
 
 
+def test_native_slab_sweep_windows_fall_back_when_cells_wrap():
+    """pbf_slab_step sweeps only the owned cell planes plus the ghost planes an iteration still
+    needs -- a run of slots of the cell-sorted arrays, as long as no cell wraps around the
+    rank-local grid in x.  Two stray owned particles placed exactly one grid period away from each
+    rank's OUTERMOST ghost plane (never inside a sweep window) wrap onto it: the windows must
+    switch themselves off for those sub-steps, and the result stays bit-identical with the
+    single-domain oracle."""
+    import threading
+    from fluidsimulation_amd import slab as S
+    from oracle import pyoracle
+    from tests.slab_common import slab_scene
+    world, layers, steps = 2, 4, 3
+    p, pos, mass, cols, vel = slab_scene(nx=60, ny=6, nz=6, iterations=3)
+    planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    q0 = S.rank_local_params(p, pos, planes, 0, world, headroom=3.0, ghost_layers=layers)
+    q1 = S.rank_local_params(p, pos, planes, 1, world, headroom=3.0, ghost_layers=layers)
+    sp = float(p.grid_spacing)
+    y, z = float(pos[:, 1].mean()), float(pos[:, 2].mean())
+    stray = np.array([[(planes[1] + layers - 1 - q0.grid_dim[0] + 0.5) * sp, y, z],      # owned by rank 0
+                      [(planes[1] - layers + q1.grid_dim[0] + 0.5) * sp, y, z]], np.float32)  # by rank 1
+    assert S.cell_x(stray[0:1, 0], sp)[0] < planes[1] <= S.cell_x(stray[1:2, 0], sp)[0]
+    pos2 = np.concatenate([pos, stray]).astype(np.float32)
+    vel2 = np.concatenate([vel, np.zeros((2, 3), np.float32)])
+    uid = RcclComm.local_id()
+    out, errs = {}, []
+
+    def rank_main(rank):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                q = q0 if rank == 0 else q1         # grids sized WITHOUT the strays: they wrap
+                b = S.HipSlabBackend(q, cols, mass, planes[rank], planes[rank + 1], device=0, ghost_layers=layers)
+                S.populate(b, pos2, mass, np.arange(pos2.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
+                           p.grid_spacing, vel=vel2)
+                comm = RcclComm(uid, rank, world, 0)
+                b.ctx.slab_attach(comm, -1 if rank == 0 else 0, -1 if rank == 1 else 1, b.max_records)
+                for _ in range(steps):
+                    b.ctx.slab_step(DT)
+                b.sync()
+                out[rank] = b.export()
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs
+    rec = np.concatenate([out[r] for r in range(world)], axis=0)
+    order = np.argsort(S.record_ids(rec))
+    o = pyoracle.Oracle(p)
+    o.upload(pos2, vel=vel2, uniform_mass=mass)
+    o.set_colliders(cols)
+    for _ in range(steps):
+        o.step(DT)
+    op, ov, _, _ = o.download()
+    assert rec.shape[0] == pos2.shape[0]
+    assert np.array_equal(rec[order, 0:3], op) and np.array_equal(rec[order, 4:7], ov)
+
+
 def test_c4_16m_particles_four_native_slabs_equal_one_ctx():
     """C4 at full size (256x250x250 = 16 000 000 particles, 4 iterations): four slabs stepped by
     pbf_slab_step (rank threads over the loopback transport, all on this one GPU) against ONE

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(BLOCK) void k_predict(const float4* __restrict__ po
                                                    uint32_t* __restrict__ key,
                                                    uint32_t* __restrict__ cell_count, uint32_t n,
                                                    float dt, float gx, float gy, float gz,
-                                                   ColliderSet cs, GridConsts G) {
+                                                   ColliderSet cs, GridConsts G, int keep_vel) {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const bool active = i < n;
     uint32_t k = 0xffffffffu;
@@ -251,7 +251,9 @@ __global__ __launch_bounds__(BLOCK) void k_predict(const float4* __restrict__ po
         float4 v = vel[i];
         float vx, vy, vz, qx, qy, qz;
         predict_one(p, v, dt, gx, gy, gz, cs, vx, vy, vz, qx, qy, qz);
-        vel[i] = make_float4(vx, vy, vz, 0.f);
+        // the predicted velocity is dead when the sub-step ends in the fused velocity update
+        // (v = (new - p) / dt reads no velocity): then it is neither stored nor sorted
+        if (keep_vel) vel[i] = make_float4(vx, vy, vz, 0.f);
         prd[i] = make_float4(qx, qy, qz, 0.f);
         k = cell_key(G, floor_cell(qx, G.spacing), floor_cell(qy, G.spacing),
                      floor_cell(qz, G.spacing));
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(BLOCK) void k_reorder(
     uint32_t dst = a + rank;
     if (slot_of) slot_of[src] = dst;
     pos_out[dst] = pos_in[src];
-    vel_out[dst] = vel_in[src];
+    if (vel_out) vel_out[dst] = vel_in[src];
     prd_out[dst] = prd_in[src];
     id_out[dst] = my;
 }
@@ -1383,6 +1385,7 @@ constexpr int SPLIT_TILES = SPLIT_ITEMS * (BLOCK / 64);   // wave-sized tiles pe
 struct PredictArgs {
     float dt, gx, gy, gz;
     ColliderSet cs;
+    int keep_vel;   // 0: the stayers' velocities are dead (see k_predict) and are not stored
 };
 
 template <bool PREDICT>
@@ -1492,7 +1495,7 @@ __global__ __launch_bounds__(BLOCK) void k_slab_split(
         if (stay) {
             const uint32_t s = block_base[0] + tile[0][t] + (uint32_t)__popcll(ms & lt);
             pos_o[s] = p;
-            vel_o[s] = v;
+            if (!PREDICT || A.keep_vel) vel_o[s] = v;
             prd_o[s] = q;
             id_o[s] = pid;
             key_o[s] = ck;
@@ -1974,7 +1977,8 @@ int set_device(pbf_ctx* c) {
     } while (0)
 
 // sort + neighbour table of the live prd (histogram must already be in cell_count)
-int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true) {
+// move_vel = false: the velocities are dead (see k_predict) and stay where they are
+int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = true) {
     const uint32_t n = c->n;
     GridConsts G = make_grid(c->P);
     {
@@ -1995,7 +1999,8 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true) {
                                                            c->tmp_src, c->tmp_id);
             k_reorder<<<nblocks(n), BLOCK, 0, c->stream>>>(
                 c->key, c->cell_start, c->tmp_src, c->tmp_id, n, c->pos[s], c->vel[s],
-                c->prd[ps_], c->pos[d], c->vel[d], c->prd[pd], c->id[d], c->slab ? c->slot_of : nullptr);
+                c->prd[ps_], c->pos[d], move_vel ? c->vel[d] : nullptr, c->prd[pd], c->id[d],
+                c->slab ? c->slot_of : nullptr);
             c->cur = d;
             c->prd_cur = pd;
         }
@@ -2475,14 +2480,14 @@ int pbf_get_boundary_neighbors(pbf_ctx* c, uint32_t* fluid_counts, uint32_t* flu
     return PBF_OK;
 }
 
-int pbf_predict(pbf_ctx* c, float dt) {
+static int predict_impl(pbf_ctx* c, float dt, bool keep_vel) {
     ENTER(c);
     if (c->keyed) HIP_CK(c, hipMemsetAsync(c->cell_count, 0, (size_t)c->ncell * 4, c->stream));
     if (c->n) {
         PhaseScope ps(c, PH_PREDICT);
         k_predict<<<nblocks(c->n), BLOCK, 0, c->stream>>>(
             c->pos[c->cur], c->vel[c->cur], c->prd[c->prd_cur], c->key, c->slab ? nullptr : c->cell_count, c->n, dt,
-            c->P.gravity[0], c->P.gravity[1], c->P.gravity[2], c->colliders, make_grid(c->P));
+            c->P.gravity[0], c->P.gravity[1], c->P.gravity[2], c->colliders, make_grid(c->P), keep_vel ? 1 : 0);
         LAUNCH_CK(c);
     }
     c->keyed = !c->slab;
@@ -2491,7 +2496,9 @@ int pbf_predict(pbf_ctx* c, float dt) {
     return PBF_OK;
 }
 
-int pbf_build_grid(pbf_ctx* c) {
+int pbf_predict(pbf_ctx* c, float dt) { return predict_impl(c, dt, true); }
+
+static int build_grid_impl(pbf_ctx* c, bool move_vel) {
     ENTER(c);
     if (c->split_pending || c->in_exchange)
         return fail(c, PBF_ERR_INVALID, "slab exchange in flight: split_done / append_ghosts come first");
@@ -2501,8 +2508,10 @@ int pbf_build_grid(pbf_ctx* c) {
                                                                 c->n, make_grid(c->P), first);
         LAUNCH_CK(c);
     }
-    return sort_and_neighbors(c);
+    return sort_and_neighbors(c, true, move_vel);
 }
+
+int pbf_build_grid(pbf_ctx* c) { return build_grid_impl(c, true); }
 
 int pbf_compute_rest_density(pbf_ctx* c) {
     ENTER(c);
@@ -2751,7 +2760,7 @@ int pbf_slab_set_bounds(pbf_ctx* c, int32_t x_lo, int32_t x_hi, int32_t ghost_la
 
 static int slab_split_impl(pbf_ctx* c, void* d_mig_left, void* d_mig_right, void* d_ghost_left,
                            void* d_ghost_right, uint32_t max_records, void* d_counts, bool predict,
-                           float dt, bool compact_ghosts = false) {
+                           float dt, bool compact_ghosts = false, bool keep_vel = true) {
     ENTER(c);
     if (!c->slab) return fail(c, PBF_ERR_INVALID, "pbf_slab_set_bounds has not been called");
     if (c->split_pending) return fail(c, PBF_ERR_INVALID, "pbf_slab_split_done has not been called");
@@ -2774,6 +2783,7 @@ static int slab_split_impl(pbf_ctx* c, void* d_mig_left, void* d_mig_right, void
         A.gy = c->P.gravity[1];
         A.gz = c->P.gravity[2];
         A.cs = c->colliders;
+        A.keep_vel = keep_vel ? 1 : 0;
         const uint32_t grid = (c->n + SPLIT_CHUNK - 1) / SPLIT_CHUNK;
 #define LAUNCH_SPLIT(PRED_)                                                                             \
     k_slab_split<PRED_><<<grid, BLOCK, 0, c->stream>>>(                                                 \
@@ -3024,7 +3034,11 @@ int pbf_slab_step(pbf_ctx* c, float dt) {
     // ghosts travel as one float4 each unless a later stage reads their velocity / old position
     // (viscosity) or masses differ; every rank takes the same decision from the shared parameters
     const bool compact = c->uniform && c->P.vorticity_eps == 0.f && c->P.xsph_c == 0.f;
-    int rc = slab_split_impl(c, c->x_mig[0], c->x_mig[1], c->x_gh[0], c->x_gh[1], c->link_max, c->x_counts, true, dt, compact);
+    // the sub-step ends in the fused velocity update, which reads no velocity: the predicted ones
+    // are neither stored nor sorted (records still carry them)
+    const bool vel_dead = can_fuse_finalize(c);
+    int rc = slab_split_impl(c, c->x_mig[0], c->x_mig[1], c->x_gh[0], c->x_gh[1], c->link_max, c->x_counts, true, dt,
+                             compact, !vel_dead);
     if (rc) return rc;
     // counts to the neighbours device-to-device, then the ONE read-back of the sub-step
     {
@@ -3059,7 +3073,7 @@ int pbf_slab_step(pbf_ctx* c, float dt) {
     if (c->bcount[0] > c->link_max || c->bcount[1] > c->link_max || c->ghost_count[0] > c->link_max ||
         c->ghost_count[1] > c->link_max)
         return fail(c, PBF_ERR_CAPACITY, "halo exceeds the exchange buffers (pbf_slab_attach max_records)");
-    if ((rc = pbf_build_grid(c))) return rc;
+    if ((rc = build_grid_impl(c, !vel_dead))) return rc;
     auto halo = [&](int32_t what) {
         return pbf_slab_halo_exchange(c, comm, what, L, R, c->x_hsend[0], c->x_hsend[1], c->x_hrecv[0], c->x_hrecv[1]);
     };
@@ -3157,9 +3171,10 @@ int pbf_slab_export(pbf_ctx* c, void* d_records, uint32_t max_records, uint32_t*
 
 int pbf_step(pbf_ctx* c, float dt) {
     ENTER(c);
-    int rc = pbf_predict(c, dt);
+    const bool vel_dead = can_fuse_finalize(c);   // the last delta-p launch rewrites every velocity
+    int rc = predict_impl(c, dt, !vel_dead);
     if (rc) return rc;
-    rc = sort_and_neighbors(c);
+    rc = sort_and_neighbors(c, true, !vel_dead);
     if (rc) return rc;
     if (c->first_frame) {
         rc = pbf_compute_rest_density(c);

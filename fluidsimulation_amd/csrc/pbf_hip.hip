@@ -821,8 +821,10 @@ __global__ __launch_bounds__(BLOCK) void k_lambda(float4* prd, const float4* __r
     float C = dens / rho0 - 1.f;
     float lam = -C;
     lam /= grad_sum + kc.epsilon;
-    dens_out[i] = dens;
-    C_out[i] = C;
+    if (dens_out) {   // per-particle rho / C are outputs for the caller only: no kernel reads them
+        dens_out[i] = dens;
+        C_out[i] = C;
+    }
     reinterpret_cast<float*>(prd)[4 * (size_t)i + 3] = lam;
 }
 
@@ -2554,7 +2556,10 @@ static bool slab_window(const pbf_ctx* c, int32_t depth, uint32_t* key_a, uint32
 
 // ghost_depth >= 0 (slab mode): sweep only the owned cell planes plus that many ghost planes per
 // side (sweep_index); -1: every particle
-static int solve_half(pbf_ctx* c, int half, float dt, bool fuse_finalize = false, int32_t ghost_depth = -1) {
+// keep_scalars = false: rho_i / C_i of this lambda sweep are not stored (a later sweep of the same
+// sub-step overwrites them before anyone can read them)
+static int solve_half(pbf_ctx* c, int half, float dt, bool fuse_finalize = false, int32_t ghost_depth = -1,
+                      bool keep_scalars = true) {
     const KernConsts kc = make_kern(c->P, dt);
     const uint32_t nb = nblocks(c->n);
     const uint32_t* win_start = nullptr;
@@ -2566,9 +2571,9 @@ static int solve_half(pbf_ctx* c, int half, float dt, bool fuse_finalize = false
         PhaseScope ps(c, PH_LAMBDA);
 #define LAUNCH_LAMBDA(U, G, B)                                                                \
     k_lambda<U, G, B><<<nb, BLOCK, 0, c->stream>>>(x, c->pos[c->cur], c->nbr, c->nbr_count, c->n, \
-                                                   c->cap, kc, c->rho0, c->uniform_mass, c->dens, \
-                                                   c->C, c->bpos, c->fb, c->fb_count, win_start,  \
-                                                   win_a, win_b, c->flags)
+                                                   c->cap, kc, c->rho0, c->uniform_mass,          \
+                                                   keep_scalars ? c->dens : nullptr, c->C, c->bpos, \
+                                                   c->fb, c->fb_count, win_start, win_a, win_b, c->flags)
 #define LAUNCH_LAMBDA_UG(U, G)            \
     do {                                  \
         if (c->nb) LAUNCH_LAMBDA(U, G, true); \
@@ -3092,7 +3097,7 @@ int pbf_slab_step(pbf_ctx* c, float dt) {
         const bool last = it + 1 == c->iterations;
         const int32_t depth_l = !local_sweeps ? -1 : (last ? 1 : valid - 1);
         const int32_t depth_d = !local_sweeps ? -1 : (last ? 0 : valid - 2);
-        if (c->n && (rc = solve_half(c, 0, dt, false, depth_l))) return rc;
+        if (c->n && (rc = solve_half(c, 0, dt, false, depth_l, last))) return rc;
         if (!local_sweeps && (rc = halo(PBF_HALO_PRED_LAMBDA))) return rc;
         if (c->n && (rc = solve_half(c, 1, dt, last && fused, depth_d))) return rc;
         if (local_sweeps) valid -= 2;
@@ -3183,8 +3188,9 @@ int pbf_step(pbf_ctx* c, float dt) {
     }
     if (can_fuse_finalize(c)) {
         for (int32_t it = 0; it < c->iterations; ++it) {
-            if ((rc = solve_half(c, 0, dt))) return rc;
-            if ((rc = solve_half(c, 1, dt, it + 1 == c->iterations))) return rc;
+            const bool last = it + 1 == c->iterations;
+            if ((rc = solve_half(c, 0, dt, false, -1, last))) return rc;
+            if ((rc = solve_half(c, 1, dt, last))) return rc;
         }
         return PBF_OK;
     }

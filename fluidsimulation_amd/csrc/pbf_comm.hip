@@ -188,21 +188,20 @@ int local_batch(pbf_comm* c, hipStream_t s, const pbf_p2p* ops, uint32_t n_ops) 
     }
     // 3. my sends: the stream must not run past the batch before the receivers have copied
     for (auto& m : mine) {
-        std::unique_lock<std::mutex> lk(G.mu);
-        if (!G.cv.wait_for(lk, std::chrono::seconds(60), [&] { return m->consumed; })) {
-            if (rc == PBF_OK) rc = comm_fail(c, PBF_ERR_INVALID, "loopback: a send was not received within 60 s");
-            continue;   // the events leak; the run is lost anyway
+        bool failed;
+        {
+            std::unique_lock<std::mutex> lk(G.mu);
+            if (!G.cv.wait_for(lk, std::chrono::seconds(60), [&] { return m->consumed; })) {
+                if (rc == PBF_OK) rc = comm_fail(c, PBF_ERR_INVALID, "loopback: a send was not received within 60 s");
+                continue;   // the receiver may still use the events: they leak; the run is lost anyway
+            }
+            failed = m->failed;
         }
-        lk.unlock();
-        if (!m->failed && hipStreamWaitEvent(s, m->done, 0) != hipSuccess && rc == PBF_OK)
+        if (!failed && hipStreamWaitEvent(s, m->done, 0) != hipSuccess && rc == PBF_OK)
             rc = comm_fail(c, PBF_ERR_HIP, "loopback: hipStreamWaitEvent failed");
-    }
-    // events are destroyed lazily by the runtime once their work has completed
-    for (auto& m : mine) {
-        if (m->consumed) {
-            (void)hipEventDestroy(m->ready);
-            (void)hipEventDestroy(m->done);
-        }
+        // destroyed lazily by the runtime once the work recorded behind them has completed
+        (void)hipEventDestroy(m->ready);
+        (void)hipEventDestroy(m->done);
     }
     return rc;
 }

@@ -1419,25 +1419,23 @@ __global__ __launch_bounds__(BLOCK) void k_slab_split(
         }
     };
     // per item: bits 0-1 class (0 none, 1 stay, 2 to the left, 3 to the right), bit 2 / 3 = in
-    // the left / right boundary planes
+    // the left / right boundary planes.  The state of every item stays in registers between the
+    // classification and the write-out (one read of pos / vel / id per particle).
     uint32_t flags = 0;
     uint32_t too_far = 0;
+    float4 P[SPLIT_ITEMS], V[SPLIT_ITEMS], Q[SPLIT_ITEMS];
+    uint32_t ID[SPLIT_ITEMS];
 #pragma unroll
     for (int k = 0; k < SPLIT_ITEMS; ++k) {
         const uint32_t i = chunk0 + k * BLOCK + threadIdx.x;
         uint32_t pid = GHOST_BIT;
         if (i < n) pid = id[i];
+        ID[k] = pid;
+        P[k] = V[k] = Q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         uint32_t f = 0;
         if (!(pid & GHOST_BIT)) {
-            float qx;
-            if (PREDICT) {
-                float4 p, v, q;
-                state(i, p, v, q);
-                qx = q.x;
-            } else {
-                qx = prd[i].x;
-            }
-            const int32_t cx = floor_cell(qx, spacing);
+            state(i, P[k], V[k], Q[k]);
+            const int32_t cx = floor_cell(Q[k].x, spacing);
             if (cx < x_lo) {
                 f = 2;
                 too_far += (int64_t)cx < (int64_t)x_lo - (hi0 - lo0);
@@ -1477,16 +1475,11 @@ __global__ __launch_bounds__(BLOCK) void k_slab_split(
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SPLIT_ITEMS; ++k) {
-        const uint32_t i = chunk0 + k * BLOCK + threadIdx.x;
         const uint32_t f = (flags >> (4 * k)) & 15u;
         const bool stay = (f & 3u) == 1u, in0 = f & 4u, in1 = f & 8u;
         const unsigned long long ms = __ballot(stay), m0 = __ballot(in0), m1 = __ballot(in1);
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), v = p, q = p;
-        uint32_t pid = 0;
-        if (f) {
-            state(i, p, v, q);
-            pid = id[i];
-        }
+        const float4 p = P[k], v = V[k], q = Q[k];
+        const uint32_t pid = ID[k];
         // cell key + histogram of the stayers (every lane takes part in the wave-level run search)
         uint32_t ck = 0xffffffffu;
         if (stay)

@@ -76,6 +76,6 @@ def test_no_gpu_means_loud_failure_not_fallback():
 def test_product_package_never_touches_the_oracle():
     """the oracle is test infrastructure: nothing under fluidsimulation_amd/ may import or link it"""
     for f in (ROOT / "fluidsimulation_amd").rglob("*"):
-        if f.suffix in {".py", ".hip", ".h", ".hpp", ".cpp", ".c"} or f.name == "Makefile":
+        if f.suffix in {".py", ".hip", ".inc", ".h", ".hpp", ".cpp", ".c"} or f.name == "Makefile":
             text = f.read_text(errors="ignore")
             assert "pyoracle" not in text and "pbf_oracle" not in text and "orc_" not in text, f

@@ -234,6 +234,58 @@ def test_constraint_solver_equals_compiled_reference(mode):
         assert lam.tobytes() == o.constraint_lambdas().tobytes()
 
 
+# ------------------------------------------------------------------ fixtures made by the compiled reference
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def _colliders_of(z):
+    return [B.plane(tuple(z["collider_a"][j]), float(z["collider_d"][j])) if int(z["collider_type"][j]) == B.PBF_COLLIDER_PLANE
+            else B.aabb(tuple(z["collider_a"][j]), tuple(z["collider_b"][j])) for j in range(len(z["collider_type"]))]
+
+
+@pytest.mark.parametrize("name", ["ref_constraints_pbd", "ref_constraints_xpbd"])
+def test_oracle_reproduces_reference_constraint_fixture(name):
+    """tests/golden/ref_constraints_*.npz hold the output of the reference's own compiled
+    ConstraintSolver / DistanceConstraint (tests/golden/make_ref_golden.py): the restatement must
+    reproduce it bit for bit -- also where /root/reference and oracle/_ref are absent"""
+    z = np.load(GOLDEN / f"{name}.npz")
+    p = B.default_params()
+    p.capacity = z["x"].shape[0]
+    p.solver_iterations = int(z["iterations"])
+    o = pyoracle.Oracle(p)
+    o.upload(z["x"], mass=z["mass"])
+    o.set_array("pred", z["x"])
+    cons = [(int(a), int(b), float(r), float(s), float(c)) for a, b, r, s, c in
+            zip(z["p0"], z["p1"], z["rest"], z["stiffness"], z["compliance"])]
+    xpbd = int(z["mode"]) == 1
+    o.set_distance_constraints(cons, B.PBF_CONSTRAINTS_XPBD if xpbd else B.PBF_CONSTRAINTS_PBD)
+    o.project_constraints(float(z["dt"]))
+    assert o.download()[3].tobytes() == z["x_out"].tobytes()
+    if xpbd:
+        assert o.constraint_lambdas().tobytes() == z["lambdas"].tobytes()
+
+
+def test_oracle_reproduces_reference_collision_fixture():
+    """tests/golden/ref_collision.npz: ParticleSet::TestCollision / OnCollision / Update of the
+    compiled reference on 2000 particles against four planes and one AABB"""
+    z = np.load(GOLDEN / "ref_collision.npz")
+    p = B.default_params()
+    p.capacity = z["pos"].shape[0]
+    p.gravity[:] = [0, 0, 0]
+    o = pyoracle.Oracle(p)
+    o.upload(z["pos"], vel=z["vel"], uniform_mass=1.0)
+    o.set_colliders(_colliders_of(z))
+    o.predict_positions(float(z["dt"]))
+    o.collision_detection(float(z["dt"]))
+    _, v, q, new = o.download()
+    assert v.tobytes() == z["vel_out"].tobytes()
+    assert q.tobytes() == z["pred_out"].tobytes() and new.tobytes() == z["new_out"].tobytes()
+    o.apply_solver_results(float(z["dt"]))
+    pos, vel, _, _ = o.download()
+    assert pos.tobytes() == z["pos_updated"].tobytes() and vel.tobytes() == z["vel_updated"].tobytes()
+
+
 # ------------------------------------------------------------------ search
 
 def _jittered(nx, ny, nz, amp, seed):

@@ -71,7 +71,10 @@ def parse():
                     help="oracle sub-steps to time on the same block as the GPU (about 10 s of CPU work; 0 = skip)")
     ap.add_argument("--cpu-block", type=int, nargs=3, default=None)
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--ghost-layers", type=int, default=4)
+    ap.add_argument("--ghost-layers", type=int, default=0,
+                    help="ghost cell planes per slab side for N>1; 0 = time 4 (one halo refresh per sub-step) and "
+                         "2 (three, half the ghost particles) on this machine's links before the run and keep "
+                         "the faster; results are bit-identical either way")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with several ranks sharing one GPU "
                          "(payloads staged through the host); numbers from it are not bench results")
@@ -156,15 +159,47 @@ def main():
         # ghost_layers = 4: one halo refresh per sub-step instead of three (slab.py, "communication-
         # avoiding halo"); transport: grouped ncclSend/ncclRecv from the C-ABI library when the
         # group runs on nccl (torch.distributed stays the bootstrap and the fallback)
-        sim = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local,
-                             ghost_layers=a.ghost_layers)
+        def time_steps(step, sync, k):
+            sync(); torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step(DT)
+            sync(); torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                             device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every rank sees the same figure
+            return float(t.item()) / k
+
+        layers, tuning = a.ghost_layers, None
+        if layers > 0:
+            sim = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=layers)
+        else:
+            # the trade between ghost work and exchange rounds depends on the links: measure it here.
+            # Both candidates share one communicator; the slower one is dropped, the faster carries on.
+            first = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=4)
+            shared = getattr(first.group.exchange, "comm", None)
+            second = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=2,
+                                    comm=shared, transport="torch" if shared is None else "auto")
+            tuning = {}
+            for cand in (first, second):
+                for _ in range(5):
+                    cand.step(DT)
+                tuning[cand.ghost_layers] = time_steps(cand.step, cand.sync, 15)
+            layers = min(tuning, key=tuning.get)
+            sim, loser = (first, second) if layers == first.ghost_layers else (second, first)
+            loser.sync()
+            if sim is second and shared is not None:   # the communicator now belongs to the survivor
+                first.owns_comm, second.owns_comm = False, True
+            del loser
         n_total = pos.shape[0]
         stepper = sim.step
         syncer = sim.sync
         ctx = sim.ctx
         workload = (f"{block[0] * world}x{block[1]}x{block[2]} dam-break block ({n_total} particles) in "
                     f"{world} x-slabs, {a.iters} solver iterations, dt=5e-4")
-        parallelism = f"slab{world}, {a.ghost_layers} ghost layers, transport {sim.transport}"
+        parallelism = f"slab{world}, {layers} ghost layers" + \
+            (f" (picked from ms/sub-step {({k: round(v * 1e3, 4) for k, v in tuning.items()})})" if tuning else "") + \
+            f", transport {sim.transport}"
 
     def barrier():
         syncer()

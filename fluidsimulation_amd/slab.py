@@ -557,7 +557,10 @@ class SlabSimulation:
     """What bench.py and multi-GPU callers use: this rank's slab of a scene, over RCCL."""
 
     def __init__(self, params: PbfParams, pos, mass, colliders, rank, world, device=0, vel=None,
-                 headroom=1.5, rebalance_every=0, ghost_layers=GHOST_LAYERS, transport="auto", native_step=True):
+                 headroom=1.5, rebalance_every=0, ghost_layers=GHOST_LAYERS, transport="auto", native_step=True,
+                 comm=None):
+        """comm: an RcclComm of this rank to share with other SlabSimulations of the same group (it
+        stays the caller's to close); None = create one when the transport asks for it"""
         import torch.distributed as dist
         planes = split_planes(pos, params.grid_spacing, world, min_width=2 * ghost_layers)
         self.planes = planes
@@ -570,7 +573,11 @@ class SlabSimulation:
                                   params.grid_spacing, vel=vel)
         self.transport = "torch.distributed"
         exchange = None
-        if transport in ("rccl", "auto") and dist.get_backend() == "nccl":
+        self.owns_comm = comm is None
+        if comm is not None:
+            exchange = P2PExchange(comm, rank, world)
+            self.transport = "rccl (C ABI)"
+        elif transport in ("rccl", "auto") and dist.get_backend() == "nccl":
             try:
                 exchange = P2PExchange(make_rccl_comm(rank, world, device), rank, world)
                 self.transport = "rccl (C ABI)"
@@ -648,7 +655,7 @@ class SlabSimulation:
             self.backend.sync()
         finally:
             comm = getattr(self.group.exchange, "comm", None)
-            if comm is not None and hasattr(comm, "close"):
+            if self.owns_comm and comm is not None and hasattr(comm, "close"):
                 comm.close()
 
     def export(self):

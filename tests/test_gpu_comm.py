@@ -307,7 +307,24 @@ def test_slab_simulation_bootstraps_the_native_path_on_an_nccl_group():
         p1, v1, _ = g.download()
         assert np.array_equal(gpos, p1) and np.array_equal(gvel, v1)
         assert sim.owned_counts() == [pos.shape[0]]
-        sim.close()
+        # bench.py's ghost-depth tuning: a second simulation of the same scene on the SAME
+        # communicator; the one that is dropped must leave the communicator to the survivor
+        other = SlabSimulation(p, pos, mass, cols, rank=0, world=1, device=0, ghost_layers=2,
+                               comm=sim.group.exchange.comm)
+        assert other.native and not other.owns_comm
+        for _ in range(5):
+            other.step(DT)
+        other.sync()
+        assert np.array_equal(other.export()[1], p1)
+        sim.sync()
+        sim.owns_comm, other.owns_comm = False, True
+        sim.close()          # does not destroy the shared communicator
+        del sim
+        other.step(DT)
+        g.step(DT)
+        other.sync()
+        assert np.array_equal(other.export()[1], g.download()[0])
+        other.close()
     finally:
         dist.destroy_process_group()
 

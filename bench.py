@@ -21,7 +21,6 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import numpy as np  # noqa: E402
 
 DT = 0.0005
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -138,7 +137,6 @@ def main():
             dist.init_process_group("gloo")
 
     from fluidsimulation_amd import PbfContext, scenes
-    from fluidsimulation_amd import binding as B
 
     block = tuple(a.block) if a.block else (100, 100, 100)
 

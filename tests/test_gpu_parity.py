@@ -8,7 +8,7 @@ centre of mass within 1%.
 import numpy as np
 import pytest
 
-from fluidsimulation_amd import PbfContext, PbfError, aabb, plane, scenes
+from fluidsimulation_amd import PbfContext, PbfError, aabb, scenes
 from fluidsimulation_amd import binding as B
 from oracle import pyoracle
 

@@ -3,7 +3,6 @@
 Captures 6 sub-steps (the period of the ctx's buffer rotation) on a torch stream and replays."""
 import sys, time
 from pathlib import Path
-import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 from fluidsimulation_amd import PbfContext, scenes

@@ -105,10 +105,18 @@ def cpu_baseline(block, iters, steps):
         for _ in range(k8):
             o.step(DT)
         ref8 = n * k8 / (time.perf_counter() - t0)
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), None)
+    except OSError:
+        pass
     return {
         "value": n * steps / dt,
         "unit": "particle-substeps/s",
         "cores": threads,
+        "cpu_model": model,
+        "host_cpus": os.cpu_count(),
         "value_at_8_threads": ref8,
         "kind": "port",
         "sample": f"{steps} sub-steps of the {block[0]}x{block[1]}x{block[2]} dam-break block "

@@ -223,4 +223,35 @@ __device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t cnt,
     for_each_neighbor<BATCH>(i, cnt, nbr, cap, x, i, static_cast<F&&>(f));
 }
 
+// The same walk with TWO per-particle arrays gathered per neighbour (position + velocity, position
+// + vorticity): both gathers of all BATCH neighbours are in flight before the first pair is
+// evaluated.  f(j, xj, yj).
+template <int BATCH, typename F>
+__device__ __forceinline__ void for_each_neighbor2(uint32_t i, uint32_t cnt,
+                                                   const uint32_t* __restrict__ nbr, uint32_t cap,
+                                                   const float4* __restrict__ x,
+                                                   const float4* __restrict__ y, F&& f) {
+    uint32_t jn[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) jn[u] = (uint32_t)u < cnt ? nbr[(size_t)u * cap + i] : i;
+    for (uint32_t k0 = 0; k0 < cnt; k0 += BATCH) {
+        uint32_t j[BATCH];
+        float4 xj[BATCH], yj[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            j[u] = jn[u];
+            xj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + (j[u] << 4));
+            yj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(y) + (j[u] << 4));
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const uint32_t k = k0 + BATCH + u;
+            jn[u] = k < cnt ? nbr[(size_t)k * cap + i] : i;
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u)
+            if (k0 + u < cnt) f(j[u], xj[u], yj[u]);
+    }
+}
+
 }  // namespace pbf

@@ -5,14 +5,18 @@
  * the components it calls).  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load it; the product (libpbf_hip.so) never does.
  *
- * Pinning status: SPHKernel and point/plane/AABB arithmetic are pinned against the
- * reference's own sources compiled into oracle/_ref (see oracle/Makefile,
- * tests/test_oracle_vs_ref.py); hash / flooring / derived constants are pinned by
- * source-derived known answers; the reference holds no golden
- * vectors or tests of its own, so the step loop as a whole is pinned only by
- * those pieces plus NaiveSearch == SpatialSearch.  XSPH viscosity, vorticity
- * confinement, the spiky-gradient option, the container clamp and scorr_dt_power
- * != 1 have no reference implementation: PARITY UNPINNED for those.
+ * Pinning status: pinned against the reference's own sources compiled into oracle/_ref
+ * (oracle/Makefile; tests/test_oracle.py "..._equals_compiled_reference" and the fixtures
+ * tests/golden/ref_*.npz those sources produced): SPHKernel and point/plane/AABB arithmetic,
+ * the collision response and re-prediction (ParticleSet::TestCollision / OnCollision), the
+ * velocity update (ParticleSet::Update) and the PBD / XPBD distance-constraint solve
+ * (ConstraintSolver over DistanceConstraint).  Hash / flooring / derived constants are pinned by
+ * source-derived known answers.  The reference holds no golden vectors or
+ * tests of its own and its Simulation.cpp / NeighborSearch.cpp cannot be built here, so the
+ * density / lambda / delta-p loops and the neighbour search are pinned only by those pieces
+ * plus NaiveSearch == SpatialSearch.  XSPH viscosity, vorticity confinement, the spiky-gradient
+ * option, the container clamp, scorr_dt_power != 1, the boundary-particle coupling and the DEM
+ * solver have no CPU implementation in the reference: PARITY UNPINNED for those.
  */
 #ifndef PBF_ORACLE_H_
 #define PBF_ORACLE_H_

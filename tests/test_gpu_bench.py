@@ -1,0 +1,36 @@
+"""bench.py's contract, end to end on the GPU: one JSON line on stdout with the driver's keys,
+the roofline and the cpu_baseline objects (small workload, a few steps)."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "5", "--warmup", "2", "--block", "24", "24",
+                        "24", "--cpu-steps", "2"], capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "particle-substeps/s" and d["data"] == "synthetic" and d["dtype"] == "f32"
+    n = 24 ** 3
+    assert d["config"]["particles"] == n and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(n * 5 / (d["ms_per_step"] * 5e-3), rel=1e-6)
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["unit"] == d["unit"] and "sample" in cb
+    assert d["health"]["nonfinite"] == 0 and d["health"]["neighbor_overflow"] == 0

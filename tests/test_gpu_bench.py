@@ -34,3 +34,24 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert cb["unit"] == d["unit"] and "sample" in cb
     assert d["health"]["nonfinite"] == 0 and d["health"]["neighbor_overflow"] == 0
+
+
+def test_bench_two_ranks_rehearsal_over_gloo():
+    """the N>1 code path of bench.py (scene split into slabs, ghost-depth tuning on a shared
+    transport, per-rank stepping, max-over-ranks timing, whole-scene statistics) with two ranks
+    sharing this one GPU over gloo -- a rehearsal of the launch the driver makes with nccl"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+                        "--gpus", "2", "--steps", "4", "--warmup", "2", "--block", "24", "20", "20",
+                        "--backend", "gloo"], capture_output=True, text=True, timeout=400, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["particles"] == 2 * 24 * 20 * 20
+    assert "slab2" in d["config"]["parallelism"] and "picked from" in d["config"]["parallelism"]
+    assert "REHEARSAL" in d["data"]
+    assert d["health"]["nonfinite"] == 0 and d["health"]["neighbor_overflow"] == 0

@@ -70,6 +70,9 @@ def parse():
                     help="oracle sub-steps to time on the same block as the GPU (about 10 s of CPU work; 0 = skip)")
     ap.add_argument("--cpu-block", type=int, nargs=3, default=None)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="N>1: --block is the WHOLE scene, cut into N slabs (strong scaling, e.g. BASELINE's 16 M "
+                         "case: --strong --block 256 250 250); default is weak scaling, one block per rank")
     ap.add_argument("--ghost-layers", type=int, default=0,
                     help="ghost cell planes per slab side for N>1; 0 = time 4 (one halo refresh per sub-step) and "
                          "2 (three, half the ghost particles) on this machine's links before the run and keep "
@@ -161,7 +164,8 @@ def main():
     else:
         from fluidsimulation_amd.slab import SlabSimulation
         # weak scaling: every rank brings one block; slabs along x
-        p, pos, mass, cols = scenes.dam_break(block[0] * world, block[1], block[2], iterations=a.iters)
+        scene_nx = block[0] if a.strong else block[0] * world
+        p, pos, mass, cols = scenes.dam_break(scene_nx, block[1], block[2], iterations=a.iters)
         # ghost_layers = 4: one halo refresh per sub-step instead of three (slab.py, "communication-
         # avoiding halo"); transport: grouped ncclSend/ncclRecv from the C-ABI library when the
         # group runs on nccl (torch.distributed stays the bootstrap and the fallback)
@@ -201,7 +205,7 @@ def main():
         stepper = sim.step
         syncer = sim.sync
         ctx = sim.ctx
-        workload = (f"{block[0] * world}x{block[1]}x{block[2]} dam-break block ({n_total} particles) in "
+        workload = (f"{scene_nx}x{block[1]}x{block[2]} dam-break block ({n_total} particles) in "
                     f"{world} x-slabs, {a.iters} solver iterations, dt=5e-4")
         parallelism = f"slab{world}, {layers} ghost layers" + \
             (f" (picked from ms/sub-step {({k: round(v * 1e3, 4) for k, v in tuning.items()})})" if tuning else "") + \
@@ -285,7 +289,7 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (a.strong and world > 1) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if a.backend == "nccl" else "synthetic (REHEARSAL over gloo: not a bench result)",

@@ -422,6 +422,11 @@ int check_flags(pbf_ctx* c) {
                     std::to_string(f.neighbor_overflow) + " particles exceed max_neighbors=" +
                         std::to_string(c->K) + " (largest count " + std::to_string(f.max_count) +
                         "); raise pbf_params.max_neighbors");
+    if (f.truncated_total)   // an earlier sub-step of this run: the state has been computed from cut rows
+        return fail(c, PBF_ERR_NEIGHBOR_OVERFLOW,
+                    std::to_string(f.truncated_total) + " neighbour rows were cut at max_neighbors=" +
+                        std::to_string(c->K) + " in earlier sub-steps since the last upload (largest count " +
+                        std::to_string(f.truncated_max) + "); raise pbf_params.max_neighbors");
     return PBF_OK;
 }
 

@@ -113,7 +113,8 @@ typedef struct pbf_params {
 typedef struct pbf_stats {
     uint32_t n;
     uint32_t nonfinite;          /* particles with a non-finite position                   */
-    uint32_t neighbor_overflow;  /* particles that hit max_neighbors in the last search     */
+    uint32_t neighbor_overflow;  /* particles that hit max_neighbors in the last search; if that
+                                    one was clean, rows cut in ANY sub-step since the upload   */
     uint32_t max_neighbor_count;
     double   mean_neighbor_count;
     double   mean_abs_C;         /* mean |rho_i/rho0 - 1| of the last solver iteration      */

@@ -38,3 +38,18 @@ def test_random_native_slab_runs_bit_exact_with_the_oracle():
         if not ok:
             bad.append((c, desc))
     assert not bad, bad
+
+
+def test_random_boundary_dem_and_constraint_runs_bit_exact_with_the_oracle():
+    """a fixed-seed slice of tools/fuzz_next_rows.py (boundary-particle walls, DEM,
+    distance constraints)"""
+    spec = importlib.util.spec_from_file_location("fuzz_next_rows", ROOT / "tools" / "fuzz_next_rows.py")
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(4242)
+    bad = []
+    for c in range(60):
+        ok, desc = fz.one_case(rng)
+        if not ok:
+            bad.append((c, desc))
+    assert not bad, bad

@@ -263,6 +263,30 @@ def test_spiky_gradient_option():
     assert np.array_equal(gp, op) and np.array_equal(gv, ov)
 
 
+def test_neighbor_overflow_in_an_earlier_substep_is_still_reported():
+    """rows are cut in the first sub-steps only (an expanding lattice: 6 neighbours at spacing
+    0.75, none from spacing 1.25 on, max_neighbors = 4); the run is not synchronised in between --
+    pbf_sync and the statistics after the LAST, clean sub-step must still say so"""
+    p, pos, mass, cols = scenes.c1_lattice(6, 6, 6, iterations=0)
+    p.max_neighbors = 4
+    p.gravity[:] = [0, 0, 0]
+    g = PbfContext(p, device=0)
+    centre = pos.mean(axis=0)
+    vel = ((pos - centre) * np.float32(1000.0)).astype(np.float32)      # spacing grows 0.25 per sub-step
+    g.upload(pos, vel=vel, uniform_mass=mass)
+    for _ in range(6):
+        g.step(DT)
+    st = g.stats()
+    assert st.max_neighbor_count == 0          # the last search was clean ...
+    assert st.neighbor_overflow > 0            # ... but rows were cut before
+    with pytest.raises(PbfError) as e:
+        g.sync()
+    assert e.value.code == B.PBF_ERR_NEIGHBOR_OVERFLOW and "earlier sub-steps" in str(e.value)
+    g.upload(pos, uniform_mass=mass)           # a new upload starts a clean record
+    p2 = g.stats()
+    assert p2.neighbor_overflow == 0
+
+
 def test_neighbor_overflow_is_loud():
     p, pos, mass, cols = scenes.c1_lattice(6, 6, 6)
     p.max_neighbors = 8

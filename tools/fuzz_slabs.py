@@ -31,6 +31,34 @@ def one_case(rng):
     # a plane moved by one cell hands particles over that are already one plane out: needs two ghost layers
     rebalance_at = int(rng.integers(0, steps)) if rng.random() < 0.3 and layers >= 2 else -1
     planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    desc0 = dict(world=world, layers=layers, iters=iters, dims=(nx, ny, nz), steps=steps, **kw)
+    if rng.random() < 0.3:
+        # the Python-orchestrated protocol (slab.py::SlabGroup over the public slab entry points, the
+        # fallback transport's code path), all slabs in this process
+        backends = []
+        ids = np.arange(pos.shape[0], dtype=np.uint32)
+        for r in range(world):
+            q = p.copy()
+            q.capacity = max(int(p.capacity), 4096)
+            b = S.HipSlabBackend(q, cols, mass, planes[r], planes[r + 1], device=0, max_records=int(q.capacity),
+                                 ghost_layers=layers)
+            S.populate(b, pos, mass, ids, planes[r], planes[r + 1], p.grid_spacing, vel=vel)
+            backends.append(b)
+        group = S.SlabGroup(backends, S.LocalExchange(world), iters)
+        for _ in range(steps):
+            group.step(DT)
+        for b in backends:
+            b.sync()
+        gids, gpos, gvel = group.export()
+        o = pyoracle.Oracle(p)
+        o.upload(pos, vel=vel, uniform_mass=mass)
+        o.set_colliders(cols)
+        for _ in range(steps):
+            o.step(DT)
+        op, ov, _, _ = o.download()
+        o.close()
+        ok = np.array_equal(gids, ids) and np.array_equal(gpos, op) and np.array_equal(gvel, ov)
+        return ok, dict(desc0, path="python")
     uid = RcclComm.local_id()
     out, errs = {}, []
 

@@ -195,6 +195,49 @@ def test_collision_response_and_update_equal_compiled_reference():
     assert rpos.tobytes() == p2.tobytes() and rvel.tobytes() == v2.tobytes()
 
 
+def test_random_collider_sets_equal_compiled_reference():
+    """thirty random collider lists (1-5 planes with arbitrary unit or non-unit normals and AABBs in
+    arbitrary order, overlapping) against the compiled ParticleSet::TestCollision / OnCollision"""
+    ref = _ref_with_particles()
+    rng = np.random.default_rng(31)
+    for case in range(30):
+        n = 500
+        cols, typ, a, b, d = [], [], [], [], []
+        for _ in range(int(rng.integers(1, 6))):
+            if rng.random() < 0.6:
+                nrm = rng.normal(0, 1, 3).astype(np.float32)
+                if rng.random() < 0.5:
+                    nrm = (nrm / np.linalg.norm(nrm)).astype(np.float32)
+                off = np.float32(rng.uniform(-0.5, 0.5))
+                cols.append(B.plane(tuple(float(v) for v in nrm), float(off)))
+                typ.append(B.PBF_COLLIDER_PLANE); a.append(nrm); b.append(np.zeros(3, np.float32)); d.append(off)
+            else:
+                mn = rng.uniform(-1, 0.5, 3).astype(np.float32)
+                mx = (mn + rng.uniform(0.1, 1.5, 3)).astype(np.float32)
+                cols.append(B.aabb(tuple(float(v) for v in mn), tuple(float(v) for v in mx)))
+                typ.append(B.PBF_COLLIDER_AABB); a.append(mn); b.append(mx); d.append(np.float32(0))
+        p = B.default_params()
+        p.capacity = n
+        p.gravity[:] = [0, 0, 0]
+        o = pyoracle.Oracle(p)
+        pos = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
+        vel = rng.normal(0, 50.0, (n, 3)).astype(np.float32)
+        o.upload(pos, vel=vel, uniform_mass=1.0)
+        o.set_colliders(cols)
+        o.predict_positions(DT)
+        v0, x0 = o.get_array("vel").copy(), o.get_array("pred").copy()
+        o.collision_detection(DT)
+        _, v1, x1, new1 = o.download()
+        rv, rp, rn = v0.copy(), x0.copy(), x0.copy()
+        rc = ref.ref_particleset_collide(n, _fp(pos), _fp(rv), _fp(rp), _fp(rn), DT, len(cols),
+                                         np.array(typ, np.int32).ctypes.data_as(C.POINTER(C.c_int32)),
+                                         _fp(np.array(a, np.float32)), _fp(np.array(b, np.float32)),
+                                         _fp(np.array(d, np.float32)))
+        assert rc == 0
+        assert rv.tobytes() == v1.tobytes() and rp.tobytes() == x1.tobytes() and rn.tobytes() == new1.tobytes(), case
+        o.close()
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_constraint_solver_equals_compiled_reference(mode):
     """ConstraintSolver::SolveConstraints over DistanceConstraint objects (ConstraintSolver.cpp,

@@ -2,7 +2,7 @@
 """Randomised differential run: HIP path against the CPU oracle on small random scenes with
 random parameters (block shape, iterations, jitter, velocities, per-particle masses, gradient
 kernel, viscosity, grid size / origin so that cells wrap, container on / off, extra colliders),
-a few sub-steps each, compared bit for bit.    python tools/fuzz_parity.py [cases] [seed]"""
+a few sub-steps each, compared bit for bit.    python tools/fuzz_parity.py [cases] [seed] [max block edge]"""
 import sys
 from pathlib import Path
 import numpy as np
@@ -14,8 +14,11 @@ from oracle import pyoracle
 DT = 0.0005
 
 
+MAX_EDGE = [14]
+
+
 def one_case(rng):
-    nx, ny, nz = (int(v) for v in rng.integers(3, 14, 3))
+    nx, ny, nz = (int(v) for v in rng.integers(3, MAX_EDGE[0], 3))
     kw = {}
     if rng.random() < 0.3:
         kw.update(xsph_c=float(rng.choice([0.0, 0.01, 0.05])), vorticity_eps=float(rng.choice([0.0, 2e-6, 1e-4])))
@@ -63,6 +66,8 @@ def one_case(rng):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3:
+        MAX_EDGE[0] = int(sys.argv[3])
     rng = np.random.default_rng(seed)
     bad = 0
     for c in range(cases):

@@ -70,6 +70,8 @@ def parse():
                     help="oracle sub-steps to time on the same block as the GPU (about 10 s of CPU work; 0 = skip)")
     ap.add_argument("--cpu-block", type=int, nargs=3, default=None)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--xsph", type=float, default=0.0, help="XSPH viscosity coefficient (BASELINE config 5: 0.01)")
+    ap.add_argument("--vorticity", type=float, default=0.0, help="vorticity confinement epsilon (config 5: 2e-6)")
     ap.add_argument("--strong", action="store_true",
                     help="N>1: --block is the WHOLE scene, cut into N slabs (strong scaling, e.g. BASELINE's 16 M "
                          "case: --strong --block 256 250 250); default is weak scaling, one block per rank")
@@ -152,7 +154,7 @@ def main():
     block = tuple(a.block) if a.block else (100, 100, 100)
 
     if world == 1:
-        p, pos, mass, cols = scenes.dam_break(*block, iterations=a.iters)
+        p, pos, mass, cols = scenes.dam_break(*block, iterations=a.iters, xsph_c=a.xsph, vorticity_eps=a.vorticity)
         ctx = PbfContext(p, device=local)
         ctx.upload(pos, uniform_mass=mass)
         ctx.set_colliders(cols)
@@ -165,7 +167,8 @@ def main():
         from fluidsimulation_amd.slab import SlabSimulation
         # weak scaling: every rank brings one block; slabs along x
         scene_nx = block[0] if a.strong else block[0] * world
-        p, pos, mass, cols = scenes.dam_break(scene_nx, block[1], block[2], iterations=a.iters)
+        p, pos, mass, cols = scenes.dam_break(scene_nx, block[1], block[2], iterations=a.iters, xsph_c=a.xsph,
+                                              vorticity_eps=a.vorticity)
         # ghost_layers = 4: one halo refresh per sub-step instead of three (slab.py, "communication-
         # avoiding halo"); transport: grouped ncclSend/ncclRecv from the C-ABI library when the
         # group runs on nccl (torch.distributed stays the bootstrap and the fallback)
@@ -293,7 +296,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if a.backend == "nccl" else "synthetic (REHEARSAL over gloo: not a bench result)",
-            "config": {"workload": workload, "particles": n_total, "iterations": a.iters,
+            "config": {"workload": workload + (f", XSPH {a.xsph} + vorticity {a.vorticity}" if (a.xsph or a.vorticity) else ""),
+                       "particles": n_total, "iterations": a.iters,
                        "arithmetic": "f32 state and accumulation, f64 SPH-kernel evaluation (as the reference CPU path)", "parallelism": parallelism,
                        "substeps_per_s": a.steps / elapsed},
             "hbm_roofline_frac_substep": (290 - 2 * ALGO_BYTES_PER_ITER + a.iters * ALGO_BYTES_PER_ITER) * value / (HBM_PEAK_GBS * 1e9 * world),

@@ -201,7 +201,7 @@ SYMBOLS = [
     "pbf_comm_last_error", "pbf_comm_batch", "pbf_slab_halo_exchange", "pbf_step_dem",
     "pbf_set_distance_constraints", "pbf_project_constraints", "pbf_get_constraint_lambdas",
     "pbf_comm_local_id", "pbf_slab_attach", "pbf_slab_step", "pbf_slab_owned_count",
-    "pbf_slab_append_owned_host", "pbf_slab_export_host",
+    "pbf_slab_append_owned_host", "pbf_slab_export_host", "pbf_build_cells_noalloc",
 ]
 
 _lib = None
@@ -301,6 +301,8 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_num_boundary_particles.restype = C.c_uint32
     lib.pbf_get_boundary.argtypes = [vp, vp, vp, vp]
     lib.pbf_get_boundary_neighbors.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32]
+    lib.pbf_build_cells_noalloc.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3),
+                                            C.c_float, vp, vp, vp, C.c_int, vp]
     if path is None:
         _lib = lib
     return lib

@@ -21,7 +21,7 @@
 //                   viscosity, slab, diag
 //   this file       constants, pbf_ctx, host helpers (error plumbing, profiling spans, sort_and_neighbors)
 //   abi/*.inc       the extern "C" entry points of include/pbf.h: lifecycle, boundary, substep,
-//                   slab, step, constraints, dem, readback
+//                   slab, step, constraints, dem, readback, noalloc
 // pbf_comm.hip (the RCCL / loopback transport) is a translation unit of its own.
 
 #include <hip/hip_runtime.h>
@@ -31,6 +31,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -442,5 +443,6 @@ extern "C" {
 #include "abi/constraints.inc"
 #include "abi/dem.inc"
 #include "abi/readback.inc"
+#include "abi/noalloc.inc"
 
 }  // extern "C"

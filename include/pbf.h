@@ -388,6 +388,29 @@ int pbf_slab_step(pbf_ctx* ctx, float dt);
 /* owned particles after the last sub-step (its ghosts sit behind them until the next split) */
 uint32_t pbf_slab_owned_count(const pbf_ctx* ctx);
 
+/* ---- cell binning without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers
+ * that cannot allocate device memory -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc -- and therefore cannot create a pbf_ctx.  Same result as
+ * pbf_build_grid + pbf_get_cells on a ctx with the same grid (NeighborSearch::Flooring cell of
+ * every particle, wrapped linear key, counting sort with the reference's bucket order, exclusive
+ * prefix sum), on caller-owned DEVICE buffers:
+ *   d_xyz        in : n packed float3 positions (layout of pbf_upload_device / pbf_export_positions)
+ *   d_cell_key   out: n x uint32, wrapped linear cell id by particle index
+ *   d_sorted_id  out: n x uint32, particle index stored at each sorted slot
+ *   d_cell_start out: (cells + 1) x uint32, exclusive prefix sum of the cell occupancy
+ * The histogram, the scatter cursor, the unordered scatter result and the scan's tile totals live
+ * in ONE fixed device array inside the library (12 MiB + 2 KiB on every GPU it runs on, held until
+ * the process ends), so the call performs no hipMalloc / hipFree and calls no allocating routine.
+ * Limits: n <= PBF_NOALLOC_MAX_PARTICLES and grid cells <= PBF_NOALLOC_MAX_CELLS, else
+ * PBF_ERR_CAPACITY (message: pbf_last_error(NULL)).  Asynchronous on hip_stream (hipStream_t; NULL =
+ * the null stream) of `device` (< 0 = the current device).  All calls on one GPU share that GPU's
+ * array: calls that overlap on one GPU (two streams, two threads) race -- serialise them. */
+#define PBF_NOALLOC_MAX_PARTICLES (1u << 20)
+#define PBF_NOALLOC_MAX_CELLS (1u << 20)
+int pbf_build_cells_noalloc(const void* d_xyz, uint32_t n, const int32_t grid_dim[3],
+                            const int32_t grid_origin_cell[3], float grid_spacing, void* d_cell_key,
+                            void* d_sorted_id, void* d_cell_start, int device, void* hip_stream);
+
 /* self-test (no reference counterpart): compares the kernels' 6-instruction correctly rounded
  * fp32 square root with the compiler's sqrtf over EVERY non-negative float; *mismatches must
  * be 0 (first_bad = bit pattern of the first differing input, 0xffffffff if none) */

@@ -137,8 +137,8 @@ struct pbf_ctx {
     float *x_mig[2] = {nullptr, nullptr}, *x_gh[2] = {nullptr, nullptr};      // out: records
     float *x_rmig[2] = {nullptr, nullptr}, *x_rgh[2] = {nullptr, nullptr};    // in: records
     float4 *x_hsend[2] = {nullptr, nullptr}, *x_hrecv[2] = {nullptr, nullptr};
-    uint32_t *x_counts = nullptr;       // device: 8 own counters + 4 received
-    uint32_t *x_host_counts = nullptr;  // pinned host mirror (12)
+    uint32_t *x_counts = nullptr;       // device: (1 + world) counter blocks of XC_WORDS: own, then every rank's
+    uint32_t *x_host_counts = nullptr;  // pinned host mirror of the same size
     bool owns_stream = true;
     bool uniform = false;      // every particle has uniform_mass (no per-neighbour mass gather)
     float uniform_mass = 0.f;
@@ -418,16 +418,22 @@ int check_flags(pbf_ctx* c) {
     DevFlags f;
     HIP_CK(c, hipMemcpyAsync(&f, c->flags, sizeof(f), hipMemcpyDeviceToHost, c->stream));
     HIP_CK(c, hipStreamSynchronize(c->stream));
+    // with a boundary set the fluid<->boundary tables (max_boundary_neighbors rows) share the counters
+    const std::string rows = "max_neighbors=" + std::to_string(c->K) +
+                             (c->nb ? " (fluid rows) or max_boundary_neighbors=" + std::to_string(c->Kb) +
+                                          " (fluid<->boundary rows)"
+                                    : std::string());
+    const char* cure = c->nb ? "); raise pbf_params.max_neighbors / pbf_set_boundary's max_boundary_neighbors"
+                             : "); raise pbf_params.max_neighbors";
     if (f.neighbor_overflow)
         return fail(c, PBF_ERR_NEIGHBOR_OVERFLOW,
-                    std::to_string(f.neighbor_overflow) + " particles exceed max_neighbors=" +
-                        std::to_string(c->K) + " (largest count " + std::to_string(f.max_count) +
-                        "); raise pbf_params.max_neighbors");
+                    std::to_string(f.neighbor_overflow) + " particles exceed " + rows + " (largest count " +
+                        std::to_string(f.max_count) + cure);
     if (f.truncated_total)   // an earlier sub-step of this run: the state has been computed from cut rows
         return fail(c, PBF_ERR_NEIGHBOR_OVERFLOW,
-                    std::to_string(f.truncated_total) + " neighbour rows were cut at max_neighbors=" +
-                        std::to_string(c->K) + " in earlier sub-steps since the last upload (largest count " +
-                        std::to_string(f.truncated_max) + "); raise pbf_params.max_neighbors");
+                    std::to_string(f.truncated_total) + " neighbour rows were cut at " + rows +
+                        " in earlier sub-steps since the last upload (largest count " +
+                        std::to_string(f.truncated_max) + cure);
     return PBF_OK;
 }
 

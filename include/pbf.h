@@ -301,7 +301,9 @@ int pbf_set_stream(pbf_ctx* ctx, void* hip_stream);
 /* INT32_MIN / INT32_MAX mark an open end; requires PBF_RHO0_FIXED.  ghost_layers = number of
  * boundary cell planes sent to each neighbour: 1 is enough for the neighbour sweeps; with 2 the
  * ghosts' lambda of a solver iteration is computed locally (bit-identical) and one halo
- * refresh per iteration is saved */
+ * refresh per iteration is saved.  A slab with a neighbour on both sides must be at least
+ * 2 * ghost_layers cell planes wide (PBF_ERR_INVALID otherwise): a migrant arriving from one side
+ * must not already lie in the boundary planes that face the other neighbour */
 int pbf_slab_set_bounds(pbf_ctx* ctx, int32_t x_lo, int32_t x_hi, int32_t ghost_layers);
 /* after pbf_predict, asynchronous, one pass over the slab: drops last step's ghosts; keeps the
  * particles whose predicted cell is still owned; packs the others as migrant records into
@@ -381,7 +383,13 @@ int pbf_slab_export_host(pbf_ctx* ctx, float* records, uint32_t max_records, uin
  * migrants + ghost planes, grid, iterations x { lambda, delta-p } with a ghost refresh only when
  * fewer than two valid ghost layers are left, velocity update (+ vorticity / XSPH stages).
  * Every rank of the communicator calls it once per sub-step.  The ctx's bounds may be moved
- * between sub-steps (pbf_slab_set_bounds: re-balancing). */
+ * between sub-steps (pbf_slab_set_bounds: re-balancing).
+ * Failure is collective: the sub-step's counters of EVERY rank travel to every rank (64 bytes per
+ * pair, ahead of the read-back), each rank runs all ranks' checks, and when any rank's exchange
+ * buffer or capacity is too small (PBF_ERR_CAPACITY) or a particle crossed more than ghost_layers
+ * planes (PBF_ERR_INVALID), ALL ranks skip the payload exchange and return that same error, naming
+ * the rank, from this same call -- no rank is left waiting in a receive.  The slab's state is lost
+ * then (pbf_num_particles == 0). */
 int pbf_slab_attach(pbf_ctx* ctx, pbf_comm* comm, int32_t left_rank, int32_t right_rank,
                     uint32_t max_records);
 int pbf_slab_step(pbf_ctx* ctx, float dt);

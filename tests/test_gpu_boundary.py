@@ -148,7 +148,24 @@ def test_boundary_table_overflow_is_loud():
     with pytest.raises(PbfError) as e:
         g.set_boundary(bpos, uniform_mass=bm, max_boundary_neighbors=2)
     assert e.value.code == B.PBF_ERR_NEIGHBOR_OVERFLOW
+    assert "max_boundary_neighbors=2" in str(e.value)      # names the table that overflowed
+    g.sync()                                  # ... and the failed set leaves no sticky error behind
     g.set_boundary(bpos, uniform_mass=bm)     # the default table width fits
+    g.step(DT); g.sync()
+
+
+def test_set_boundary_keeps_an_earlier_fluid_row_truncation_on_record():
+    """rows cut in an unsynchronised sub-step must still be reported after pbf_set_boundary (which
+    runs a neighbour search of its own on the same device flags)"""
+    p, pos, mass, cols, bpos, bm = scenes.boundary_tank(8, 8, 8, iterations=1)
+    p.max_neighbors = 4
+    g = PbfContext(p, device=0)
+    g.upload(pos, uniform_mass=mass)
+    g.step(DT)                                # every fluid row is cut at 4; nobody has synchronised
+    g.set_boundary(bpos, uniform_mass=bm, max_boundary_neighbors=64)
+    with pytest.raises(PbfError) as e:
+        g.sync()
+    assert e.value.code == B.PBF_ERR_NEIGHBOR_OVERFLOW and "earlier sub-steps" in str(e.value)
 
 
 def test_hip_reproduces_boundary_golden():

@@ -381,3 +381,66 @@ def test_native_slabs_with_boundary_particle_walls(world, layers):
     op, ov, _, _ = o.download()
     assert rec.shape[0] == pos.shape[0]
     assert np.array_equal(rec[order, 0:3], op) and np.array_equal(rec[order, 4:7], ov)
+
+
+def test_native_slab_step_failure_is_collective_not_a_hang():
+    """One rank of three is attached with exchange buffers far too small for its ghost planes.
+    Every rank's counters reach every rank ahead of the sub-step's read-back, so ALL THREE return
+    PBF_ERR_CAPACITY naming rank 1 from the same pbf_slab_step call -- nobody enters the payload
+    exchange, nobody is left waiting in a receive (without the all-gather rank 1 alone returned
+    and its neighbours blocked until the transport's time-out)."""
+    import threading
+    import time
+    from fluidsimulation_amd import slab as S
+    from fluidsimulation_amd import binding as B
+    from tests.slab_common import slab_scene
+    world, layers = 3, 2
+    p, pos, mass, cols, vel = slab_scene(nx=36, ny=6, nz=6, iterations=2)
+    planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    uid = RcclComm.local_id()
+    res, errs = {}, []
+
+    def rank_main(rank):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                q = S.rank_local_params(p, pos, planes, rank, world, headroom=3.0, ghost_layers=layers)
+                b = S.HipSlabBackend(q, cols, mass, planes[rank], planes[rank + 1], device=0, ghost_layers=layers)
+                S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
+                           p.grid_spacing, vel=vel)
+                comm = RcclComm(uid, rank, world, 0)
+                b.ctx.slab_attach(comm, -1 if rank == 0 else rank - 1, -1 if rank == world - 1 else rank + 1,
+                                  8 if rank == 1 else b.max_records)
+                try:
+                    b.ctx.slab_step(DT)
+                    res[rank] = (B.PBF_OK, "")
+                except PbfError as e:
+                    res[rank] = (e.code, str(e))
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=100)
+    assert not errs, errs
+    assert time.perf_counter() - t0 < 45.0, "ranks waited for a time-out: the failure was not collective"
+    assert sorted(res) == [0, 1, 2]
+    for r in range(world):
+        assert res[r][0] == B.PBF_ERR_CAPACITY and "rank 1:" in res[r][1], (r, res[r])
+    assert len({res[r][1] for r in range(world)}) == 1, "every rank reports the same failure"
+
+
+def test_slab_bounds_reject_an_interior_slab_narrower_than_two_ghost_depths():
+    from fluidsimulation_amd import binding as B
+    p, pos, mass, cols = scenes.dam_break(8, 6, 6, iterations=2)
+    g = PbfContext(p, device=0)
+    with pytest.raises(PbfError) as e:
+        g.slab_set_bounds(10, 13, 2)          # 3 planes < 2 * 2
+    assert e.value.code == B.PBF_ERR_INVALID and "2 * ghost_layers" in str(e.value)
+    g.slab_set_bounds(10, 14, 2)              # exactly 2 * ghost_layers: fine
+    g.slab_set_bounds(-2**31, 12, 4)          # an open end lifts the rule
+    g.slab_set_bounds(10, 2**31 - 1, 4)

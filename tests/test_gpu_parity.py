@@ -252,6 +252,24 @@ def test_xsph_vorticity_bit_exact_vs_own_oracle():
     assert np.array_equal(gp, op) and np.array_equal(gv, ov)
 
 
+@pytest.mark.parametrize("xsph,vort", [(0.01, 0.05), (0.0, 0.05), (0.02, 0.0)])
+def test_xsph_vorticity_with_per_particle_masses(xsph, vort):
+    """the un-packed confinement sweep (per-particle masses: the fourth slot of the gathered
+    position carries m_j, so |omega| cannot ride there) and the m_j weighting of vorticity / XSPH"""
+    p, pos, mass, cols = scenes.dam_break(11, 12, 10, iterations=2, xsph_c=xsph, vorticity_eps=vort)
+    rng = np.random.default_rng(23)
+    masses = (mass * rng.uniform(0.6, 1.5, pos.shape[0])).astype(np.float32)
+    vel = rng.normal(0, 0.5, pos.shape).astype(np.float32)
+    g, o = make_pair(p, pos, mass, cols, vel=vel, masses=masses)
+    for _ in range(3):
+        g.step(DT); o.step(DT)
+    g.sync()
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.isfinite(gp).all() and np.isfinite(gv).all()
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)
+
+
 def test_spiky_gradient_option():
     p, pos, mass, cols = scenes.dam_break(10, 10, 10, iterations=2)
     p.gradient_kernel = B.PBF_GRAD_SPIKY

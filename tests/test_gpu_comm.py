@@ -277,6 +277,53 @@ def test_c4_16m_particles_four_native_slabs_equal_one_ctx():
     assert np.array_equal(rec[order, 0:3], p1) and np.array_equal(rec[order, 4:7], v1)
 
 
+def test_c5_two_native_slabs_of_8m_particles_with_xsph_and_vorticity_equal_one_ctx():
+    """C5 at its full PER-GPU size (BASELINE config 5: 8 M particles per GPU, XSPH c = 0.01 +
+    vorticity confinement): two slabs of 8 000 000 particles (a 400x200x200 block) stepped by
+    pbf_slab_step over the loopback transport, four ghost layers, against ONE ctx on the whole
+    16 M scene -- bit-identical after two sub-steps, viscosity stages included; plus the
+    size-independent health checks (no non-finite state, no neighbour-row overflow, lattice
+    neighbour counts)."""
+    import threading
+    import torch
+    from fluidsimulation_amd import slab as S
+    p, pos, mass, cols = scenes.dam_break(400, 200, 200, iterations=4, xsph_c=0.01, vorticity_eps=2e-6)
+    n = pos.shape[0]
+    assert n == 16_000_000
+    steps, world, layers = 2, 2, 4
+    g = PbfContext(p, device=0)
+    g.upload(pos, uniform_mass=mass)
+    g.set_colliders(cols)
+    for _ in range(steps):
+        g.step(DT)
+    g.sync()
+    st = g.stats()
+    assert st.n == n and st.nonfinite == 0 and st.neighbor_overflow == 0
+    assert 15.0 < st.mean_neighbor_count < 30.0 and st.max_neighbor_count <= 64
+    p1, v1, _ = g.download()
+    assert np.isfinite(v1).all() and float(np.abs(v1).max()) > 0.0
+    del g
+    torch.cuda.empty_cache()
+    planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    owned = np.bincount(np.searchsorted(planes[1:-1], S.cell_x(pos[:, 0], p.grid_spacing), side="right"),
+                        minlength=world)
+    assert owned.min() > 7_500_000, owned          # 8 M per slab, up to the plane snapping
+    uid = RcclComm.local_id()
+    out, errs = {}, []
+    vel = np.zeros_like(pos)
+    ts = [threading.Thread(target=_native_rank, args=(r, world, uid, p, pos, mass, cols, vel, planes, layers,
+                                                      steps, out, errs, False)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not errs, errs
+    rec = np.concatenate([out[r] for r in range(world)], axis=0)
+    assert rec.shape[0] == n
+    order = np.argsort(S.record_ids(rec))
+    assert np.array_equal(rec[order, 0:3], p1) and np.array_equal(rec[order, 4:7], v1)
+
+
 def test_slab_simulation_bootstraps_the_native_path_on_an_nccl_group():
     """what bench.py --gpus N does on every rank, here with a world of one: the RCCL unique id
     travels over the torch.distributed (nccl) group, the communicator is created through the C

@@ -126,6 +126,20 @@ def load_ref():
     lib.ref_glm_dot.restype = C.c_float
     lib.ref_glm_pow.argtypes = [C.c_double, C.c_int]
     lib.ref_glm_pow.restype = C.c_double
+    if hasattr(lib, "ref_glm_distance2_many"):   # doors of tests/golden/make_ref_loops.py
+        lib.ref_glm_distance2.argtypes = [f3, f3]
+        lib.ref_glm_distance2.restype = C.c_float
+        for name in ("ref_glm_distance2_many", "ref_glm_distance_many"):
+            getattr(lib, name).argtypes = [f3, f3, C.c_uint32, f3]
+            getattr(lib, name).restype = None
+        lib.ref_poly6_w_many.argtypes = [f3, C.c_float, C.c_uint32, f3]
+        lib.ref_poly6_w_many.restype = None
+        lib.ref_poly6_w_gradient_many.argtypes = [f3, f3, f3, C.c_float, C.c_uint32, f3]
+        lib.ref_poly6_w_gradient_many.restype = None
+        lib.ref_glm_scaled_dot_self_many.argtypes = [C.c_float, f3, C.c_uint32, f3]
+        lib.ref_glm_scaled_dot_self_many.restype = None
+        lib.ref_glm_scale_many.argtypes = [f3, f3, C.c_uint32, f3]
+        lib.ref_glm_scale_many.restype = None
     # Particle.cpp / Constraints.cpp / ConstraintSolver.cpp doors (present when the image held
     # cuda_runtime.h at build time; ref_has_particles() says which build this is)
     lib.ref_has_particles.restype = C.c_int

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "SPHKernel.h"
+#include <glm/gtx/norm.hpp>
 #include "CollisionDetection.h"
 #ifdef REF_WITH_PARTICLES
 #include "Particle.h"
@@ -59,6 +60,58 @@ float ref_glm_dot(const float* a, const float* b) {
 }
 
 double ref_glm_pow(double x, int e) { return glm::pow(x, e); }
+
+// glm::distance2 as NeighborSearch.cpp:219 calls it (gtx/norm.hpp, reached through common.h)
+float ref_glm_distance2(const float* a, const float* b) {
+    return glm::distance2(glm::vec3(a[0], a[1], a[2]), glm::vec3(b[0], b[1], b[2]));
+}
+
+// The same leaf functions applied to one particle against an array of others -- each element is
+// ONE call of the reference's function; the loops of Simulation.cpp that combine them are not here
+// (tests/golden/make_ref_loops.py walks them pair by pair).
+void ref_glm_distance2_many(const float* pi, const float* pts, uint32_t n, float* out) {
+    const glm::vec3 a(pi[0], pi[1], pi[2]);
+    for (uint32_t j = 0; j < n; ++j)
+        out[j] = glm::distance2(a, glm::vec3(pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]));
+}
+
+void ref_glm_distance_many(const float* pi, const float* pts, uint32_t n, float* out) {
+    const glm::vec3 a(pi[0], pi[1], pi[2]);
+    for (uint32_t j = 0; j < n; ++j)
+        out[j] = glm::distance(a, glm::vec3(pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]));
+}
+
+void ref_poly6_w_many(const float* distance, float h, uint32_t n, float* out) {
+    for (uint32_t j = 0; j < n; ++j) out[j] = SPHKernel::Poly6_W(distance[j], h);
+}
+
+// diff = p_i - p_j (glm vec3 subtraction, Simulation.cpp:662,694), then Poly6_W_Gradient(diff, d, h)
+void ref_poly6_w_gradient_many(const float* pi, const float* pts, const float* distance, float h, uint32_t n,
+                               float* out) {
+    const glm::vec3 a(pi[0], pi[1], pi[2]);
+    for (uint32_t j = 0; j < n; ++j) {
+        const glm::vec3 diff = a - glm::vec3(pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]);
+        const glm::vec3 g = SPHKernel::Poly6_W_Gradient(diff, distance[j], h);
+        out[3 * j] = g.x; out[3 * j + 1] = g.y; out[3 * j + 2] = g.z;
+    }
+}
+
+// float * vec3 and dot(v, v) of glm, per element: s * v[j], then glm::dot of the product with itself
+// (gradientC_j = (1.f / rho0) * grad; dot_value = dot(gradientC_j, gradientC_j), Simulation.cpp:665-667)
+void ref_glm_scaled_dot_self_many(float s, const float* v, uint32_t n, float* out) {
+    for (uint32_t j = 0; j < n; ++j) {
+        const glm::vec3 g = s * glm::vec3(v[3 * j], v[3 * j + 1], v[3 * j + 2]);
+        out[j] = glm::dot(g, g);
+    }
+}
+
+// float * vec3 of glm, per element (result = s[j] * grad[j], Simulation.cpp:704-706)
+void ref_glm_scale_many(const float* s, const float* v, uint32_t n, float* out) {
+    for (uint32_t j = 0; j < n; ++j) {
+        const glm::vec3 g = s[j] * glm::vec3(v[3 * j], v[3 * j + 1], v[3 * j + 2]);
+        out[3 * j] = g.x; out[3 * j + 1] = g.y; out[3 * j + 2] = g.z;
+    }
+}
 
 #ifdef REF_WITH_PARTICLES
 int ref_has_particles(void) { return 1; }

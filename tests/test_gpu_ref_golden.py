@@ -56,3 +56,38 @@ def test_hip_predict_and_collision_response_equal_compiled_reference():
     g.finalize(float(z["dt"]))
     pos, vel, _ = g.download()
     assert pos.tobytes() == z["pos_updated"].tobytes() and vel.tobytes() == z["vel_updated"].tobytes()
+
+
+@pytest.mark.parametrize("name", ["ref_loops_c1_first_substep", "ref_loops_jitter_8x16x8"])
+def test_hip_solver_loops_equal_compiled_reference(name):
+    """tests/golden/ref_loops_*.npz (tests/golden/make_ref_loops.py: every pair evaluated by the
+    reference's compiled SPHKernel / glm, accumulated in the order of Simulation.cpp:273-300,
+    607-712 over lists ordered as NeighborSearch.cpp:194-227): the HIP path's cells, neighbour
+    table IN ORDER, first-frame rest density, rho_i, C_i, lambda_i and corrected positions of one
+    solver iteration, bit for bit, with no oracle in between."""
+    from fluidsimulation_amd import scenes
+    z = np.load(GOLDEN / f"{name}.npz")
+    n = z["pos"].shape[0]
+    p, _, _, cols = scenes.c1_lattice(2, 2, 2, iterations=1)
+    p.capacity = n
+    g = PbfContext(p, device=0)
+    g.upload(z["pos"], vel=z["vel"], uniform_mass=float(z["mass"]))
+    g.set_colliders(cols)
+    dt = float(z["dt"])
+    g.predict(dt)
+    _, v, q = g.download()
+    assert v.tobytes() == z["vel_predicted"].tobytes() and q.tobytes() == z["pred"].tobytes()
+    g.build_grid()
+    assert np.array_equal(g.cells()[0], z["cell"])
+    counts, nb = g.neighbors()
+    k = z["neighbors"].shape[1]
+    assert np.array_equal(counts, z["neighbor_counts"]) and np.array_equal(nb[:, :k], z["neighbors"])
+    assert not nb[:, k:].any()
+    g.compute_rest_density()
+    assert np.float32(g.rest_density()).tobytes() == z["rest_density"].tobytes()
+    g.solve_lambda(dt)
+    dens, Cc, lam = g.scalars()
+    assert dens.tobytes() == z["density"].tobytes() and Cc.tobytes() == z["C"].tobytes()
+    assert lam.tobytes() == z["lambdas"].tobytes()
+    g.solve_delta(dt)
+    assert g.download()[2].tobytes() == z["new_positions"].tobytes()

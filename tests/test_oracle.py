@@ -329,6 +329,39 @@ def test_oracle_reproduces_reference_collision_fixture():
     assert pos.tobytes() == z["pos_updated"].tobytes() and vel.tobytes() == z["vel_updated"].tobytes()
 
 
+@pytest.mark.parametrize("name", ["ref_loops_c1_first_substep", "ref_loops_jitter_8x16x8"])
+def test_oracle_reproduces_reference_loops_fixture(name):
+    """tests/golden/ref_loops_*.npz (tests/golden/make_ref_loops.py): neighbour lists, first-frame
+    rest density, rho_i, C_i, lambda_i and the corrected positions of one solver iteration,
+    accumulated pair by pair from calls into the reference's compiled SPHKernel / glm / ParticleSet.
+    The restated hot loops (orc_spatial_search, orc_compute_rest_density, orc_compute_density,
+    orc_compute_lambdas, orc_compute_correction) must reproduce every bit of it."""
+    z = np.load(GOLDEN / f"{name}.npz")
+    p, _, _, cols = scenes.c1_lattice(2, 2, 2, iterations=1)
+    p.capacity = z["pos"].shape[0]
+    o = pyoracle.Oracle(p)
+    o.upload(z["pos"], vel=z["vel"], uniform_mass=float(z["mass"]))
+    o.set_colliders(cols)
+    dt = float(z["dt"])
+    o.predict_positions(dt)
+    o.collision_detection(dt)
+    _, v, q, _ = o.download()
+    assert v.tobytes() == z["vel_predicted"].tobytes() and q.tobytes() == z["pred"].tobytes()
+    o.spatial_search()
+    assert np.array_equal(o.cells()[0], z["cell"])
+    counts, nb = o.neighbors(stride=z["neighbors"].shape[1])
+    assert np.array_equal(counts, z["neighbor_counts"]) and np.array_equal(nb, z["neighbors"])
+    o.compute_rest_density()
+    assert np.float32(o.rest_density()).tobytes() == z["rest_density"].tobytes()
+    o.compute_density()
+    o.compute_lambdas()
+    dens, Cc, lam = o.scalars()
+    assert dens.tobytes() == z["density"].tobytes() and Cc.tobytes() == z["C"].tobytes()
+    assert lam.tobytes() == z["lambdas"].tobytes()
+    o.compute_correction(dt)
+    assert o.download()[3].tobytes() == z["new_positions"].tobytes()
+
+
 # ------------------------------------------------------------------ search
 
 def _jittered(nx, ny, nz, amp, seed):

@@ -112,21 +112,23 @@ __device__ __forceinline__ float grad_scalar_strict(const KernConsts& k, float d
     return 0.0f;
 }
 
-// Poly6_W and the Poly6 gradient scalar of one distance in one go: they share d*d, q and q*q and
-// ONE support test (a distance is a square root: >= 0 or NaN, and NaN fails `<= h` exactly like
-// it fails the reference's `d >= 0 && d <= h`).  Same values as poly6_strict +
-// grad_scalar_strict<PBF_GRAD_POLY6>.
+// Poly6_W and the Poly6 gradient scalar of one distance in one go: they share q and q*q.
+// Same values as poly6_strict + grad_scalar_strict<PBF_GRAD_POLY6>, with two exact shortcuts:
+//  - q = fma(-d, d, h2): d holds a 24-bit value, so d * d is exact in fp64 and h2 - d * d rounds
+//    once either way;
+//  - the support test `0 <= distance <= h` becomes q = max(q, 0): distance is a square root (>= 0
+//    or NaN); distance > h  <=>  (double)d * d > (double)h * h = h2  <=>  q < 0, and a clamped q
+//    gives W = (float)(coef * 0) = 0 and a gradient scalar of g_coef * 0.f = -0.f where the
+//    reference returns +0 -- the same "0 * diff" deviation in the sign of a zero that DESIGN.md
+//    section 3 already lists (a sum only shows it when it is itself exactly -0).  NaN: max(NaN, 0) = 0,
+//    like the reference's failed test.
 __device__ __forceinline__ void poly6_pair(const KernConsts& k, float distance, float& w, float& gs) {
     const double d = (double)distance;
-    const double d2 = d * d;
-    const double q = k.h2 - d2;
+    const double q = fmax(fma(-d, d, k.h2), 0.0);
     const double q2 = q * q;
     const double q3 = q2 * q;  // (q * q) * q
-    const float wv = (float)(k.w_coef * q3);
-    const float gv = k.g_coef * (float)q2;
-    const bool in = distance <= k.h;
-    w = in ? wv : 0.0f;
-    gs = in ? gv : 0.0f;
+    w = (float)(k.w_coef * q3);
+    gs = k.g_coef * (float)q2;
 }
 
 template <int GRAD>
@@ -180,76 +182,92 @@ __device__ __forceinline__ float scorr_strict(const KernConsts& k, float w) {
     return (float)s;
 }
 
-// Visit the neighbour row of particle i in order, with BATCH row entries and BATCH position
-// gathers in flight and the next batch of row entries prefetched behind them.  f(j, xj) is
-// called in row order (the summation order of the reference, Simulation.cpp:628,660,692).
-// Row loads stay predicated on k < cnt: loading them unconditionally (measured) costs more in
-// extra row traffic than the removed branches save.
-// `dummy` is the index gathered for the masked-off tail of the last batch: any valid index of x
-// (i itself when the row points into the particle's own set).
-template <int BATCH, typename F>
-__device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t cnt,
-                                                  const uint32_t* __restrict__ nbr, uint32_t cap,
-                                                  const float4* __restrict__ x, uint32_t dummy,
-                                                  F&& f) {
-    uint32_t jn[BATCH];
-#pragma unroll
-    for (int u = 0; u < BATCH; ++u) jn[u] = (uint32_t)u < cnt ? nbr[(size_t)u * cap + i] : dummy;
-    for (uint32_t k0 = 0; k0 < cnt; k0 += BATCH) {
-        uint32_t j[BATCH];
-        float4 xj[BATCH];
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            j[u] = jn[u];
-            // 32-bit byte offset (capacity <= 2^28): one shift, and the load takes the base from
-            // scalar registers, instead of a 64-bit address per gather
-            xj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + (j[u] << 4));
-        }
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            const uint32_t k = k0 + BATCH + u;
-            jn[u] = k < cnt ? nbr[(size_t)k * cap + i] : dummy;
-        }
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u)
-            if (k0 + u < cnt) f(j[u], xj[u]);
-    }
+// ---- neighbour table layout.  The table of a set with `cap` slots holds the k-th neighbour of
+// particle i at word k * cap + i (m_search_cache transposed: row k of every particle contiguous,
+// one coalesced 256-byte read per wave).  Rows are walked four at a time; the builder
+// (k_neighbors) pads a particle's list to a multiple of four with a valid index, so a sweep loads
+// the four entries of a group without a per-entry predicate or dummy select, from a UNIFORM row
+// base (scalar registers) plus the lane's slot -- no per-entry vector address arithmetic -- and
+// the gathers of the masked-off tail never leave the target array.
+__host__ __device__ __forceinline__ uint32_t nbr_rows(uint32_t K) { return (K + 3u) & ~3u; }
+
+__device__ __forceinline__ size_t nbr_word(uint32_t k, uint32_t i, uint32_t cap) {
+    return (size_t)k * cap + i;
 }
 
+// Visit the neighbour row of particle i in order, four entries and four position gathers in
+// flight, the next four entries prefetched behind them.  f(j, xj) is called in row order (the
+// summation order of the reference, Simulation.cpp:628,660,692).
 template <int BATCH, typename F>
 __device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t cnt,
                                                   const uint32_t* __restrict__ nbr, uint32_t cap,
                                                   const float4* __restrict__ x, F&& f) {
-    for_each_neighbor<BATCH>(i, cnt, nbr, cap, x, i, static_cast<F&&>(f));
+    static_assert(BATCH == 4, "rows are padded to groups of four");
+    const uint32_t* __restrict__ rows = nbr;   // uniform: row k0 of every particle
+    const size_t c1 = cap, c2 = 2 * (size_t)cap, c3 = 3 * (size_t)cap, c4 = 4 * (size_t)cap;
+    uint32_t jn[4] = {0u, 0u, 0u, 0u};
+    if (cnt) {
+        jn[0] = rows[i];
+        jn[1] = rows[c1 + i];
+        jn[2] = rows[c2 + i];
+        jn[3] = rows[c3 + i];
+    }
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
+        const uint32_t j[4] = {jn[0], jn[1], jn[2], jn[3]};
+        float4 xj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            // 32-bit byte offset (capacity <= 2^28): one shift, and the load takes the base from
+            // scalar registers, instead of a 64-bit address per gather
+            xj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + (j[u] << 4));
+        rows += c4;
+        if (k0 + 4 < cnt) {
+            jn[0] = rows[i];
+            jn[1] = rows[c1 + i];
+            jn[2] = rows[c2 + i];
+            jn[3] = rows[c3 + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u < cnt) f(j[u], xj[u]);
+    }
 }
 
 // The same walk with TWO per-particle arrays gathered per neighbour (position + velocity, position
-// + vorticity): both gathers of all BATCH neighbours are in flight before the first pair is
+// + vorticity): both gathers of all four neighbours are in flight before the first pair is
 // evaluated.  f(j, xj, yj).
 template <int BATCH, typename F>
 __device__ __forceinline__ void for_each_neighbor2(uint32_t i, uint32_t cnt,
                                                    const uint32_t* __restrict__ nbr, uint32_t cap,
                                                    const float4* __restrict__ x,
                                                    const float4* __restrict__ y, F&& f) {
-    uint32_t jn[BATCH];
+    static_assert(BATCH == 4, "rows are padded to groups of four");
+    const uint32_t* __restrict__ rows = nbr;
+    const size_t c1 = cap, c2 = 2 * (size_t)cap, c3 = 3 * (size_t)cap, c4 = 4 * (size_t)cap;
+    uint32_t jn[4] = {0u, 0u, 0u, 0u};
+    if (cnt) {
+        jn[0] = rows[i];
+        jn[1] = rows[c1 + i];
+        jn[2] = rows[c2 + i];
+        jn[3] = rows[c3 + i];
+    }
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
+        const uint32_t j[4] = {jn[0], jn[1], jn[2], jn[3]};
+        float4 xj[4], yj[4];
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) jn[u] = (uint32_t)u < cnt ? nbr[(size_t)u * cap + i] : i;
-    for (uint32_t k0 = 0; k0 < cnt; k0 += BATCH) {
-        uint32_t j[BATCH];
-        float4 xj[BATCH], yj[BATCH];
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            j[u] = jn[u];
+        for (int u = 0; u < 4; ++u) {
             xj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + (j[u] << 4));
             yj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(y) + (j[u] << 4));
         }
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            const uint32_t k = k0 + BATCH + u;
-            jn[u] = k < cnt ? nbr[(size_t)k * cap + i] : i;
+        rows += c4;
+        if (k0 + 4 < cnt) {
+            jn[0] = rows[i];
+            jn[1] = rows[c1 + i];
+            jn[2] = rows[c2 + i];
+            jn[3] = rows[c3 + i];
         }
 #pragma unroll
-        for (int u = 0; u < BATCH; ++u)
+        for (int u = 0; u < 4; ++u)
             if (k0 + u < cnt) f(j[u], xj[u], yj[u]);
     }
 }

@@ -37,24 +37,73 @@ ALGO_BYTES_SUBSTEP_4IT = 382
 ALGO_BYTES_PER_ITER = 46           # 18 + 28
 
 
-def pmc_traffic(kernel_phase, iters=4):
-    """HBM bytes per launch of the phase's kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_latest.json, written by tools/summarize_prof.py): FETCH_SIZE counts 64-B
-    requests at half their size for wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM;
-    calibrated on k_finalize: 32 MB read -> 16 MB counted), WRITE_SIZE is exact; both in KiB."""
+PMC_KERNELS = {"lambda": "k_lambda<true, 0, false>", "delta": "k_delta<0, false, false>", "predict": "k_predict",
+               "finalize": "k_finalize", "neighbors": "k_neighbors<true>"}
+N_CU, N_SIMD, N_XCD = 256, 1024, 8     # MI355X_MICROARCH.md
+
+
+def kernel_source_sha():
+    """fingerprint of the device code the PMC passes profiled: sha256 over the kernel sources.
+    tools/summarize_prof.py stamps profiles/pmc_latest.json with it; a bench run of other sources
+    must not quote that file's counters."""
+    import hashlib
+    csrc = ROOT / "fluidsimulation_amd" / "csrc"
+    h = hashlib.sha256()
+    for f in [csrc / "pbf_hip.hip", csrc / "pbf_device.h"] + sorted(csrc.glob("kernels/*.inc")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    """profiles/pmc_latest.json (per-kernel, per-launch averages of the rocprofv3 --pmc passes), or
+    None when it is absent or was taken from other kernel sources than the ones in this tree"""
     f = ROOT / "profiles" / "pmc_latest.json"
-    names = {"lambda": "k_lambda<true, 0, false>", "delta": "k_delta<0, false, false>", "predict": "k_predict",
-             "finalize": "k_finalize", "neighbors": "k_neighbors<true>"}
     try:
         d = json.loads(f.read_text())
-        k = d["kernels"][names[kernel_phase]]
+    except Exception:
+        return None, "no profiles/pmc_latest.json"
+    if d.get("kernel_source_sha") != kernel_source_sha():
+        return None, (f"profiles/pmc_latest.json was taken from kernel sources {d.get('kernel_source_sha')}, "
+                      f"this tree is {kernel_source_sha()}: counters not quoted")
+    return d, None
+
+
+def pmc_traffic(d, kernel_phase, iters=4):
+    """HBM bytes per launch of the phase's kernel: FETCH_SIZE counts 64-B requests at half their
+    size for wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM; calibrated on k_finalize:
+    32 MB read -> 16 MB counted), WRITE_SIZE is exact; both in KiB."""
+    try:
+        k = d["kernels"][PMC_KERNELS[kernel_phase]]
         nbytes = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
         last = d["kernels"].get("k_delta<0, false, true>")
         if kernel_phase == "delta" and last and iters > 0:
             # the sub-step's last delta-p launch also carries the velocity update
             nbytes = ((iters - 1) * nbytes + (2.0 * last["FETCH_SIZE"] + last["WRITE_SIZE"]) * 1024.0) / iters
-        return {"bytes_per_launch": nbytes,
-                "particles_per_launch": d["particles_per_launch"], "source": str(f.relative_to(ROOT))}
+        return {"bytes_per_launch": nbytes, "particles_per_launch": d["particles_per_launch"]}
+    except Exception:
+        return None
+
+
+def pmc_limiters(d, kernel_phase):
+    """How busy each candidate limiter was during the kernel, from the counters alone:
+    valu = SQ_ACTIVE_INST_VALU (quad-cycles, all SIMDs) x 4 / (kernel cycles x SIMDs);
+    l1   = TCP_TOTAL_CACHE_ACCESSES / (kernel cycles x CUs)  (the vector L1 takes about one access --
+           one distinct 32-byte sector -- per clock: tools/micro/gather_cost.hip);
+    lds  = SQ_INSTS_LDS x 8 clocks (a 64-lane ds_read_b128 at 128 B/clk) / (kernel cycles x CUs);
+    hbm  = (2 FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s.
+    kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs)."""
+    try:
+        k = d["kernels"][PMC_KERNELS[kernel_phase]]
+        cyc = k["GRBM_GUI_ACTIVE"] / N_XCD
+        clock_hz = float(d.get("clock_hz") or 2.4e9)
+        out = {"valu": k["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * N_SIMD),
+               "l1": k["TCP_TOTAL_CACHE_ACCESSES_sum"] / (cyc * N_CU),
+               "lds": k.get("SQ_INSTS_LDS", 0.0) * 8.0 / (cyc * N_CU),
+               "hbm": (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 / (cyc / clock_hz) / (HBM_PEAK_GBS * 1e9),
+               "valu_insts_per_wave": k["SQ_INSTS_VALU"] / k["SQ_WAVES"],
+               "kernel_cycles": cyc}
+        return {a: (round(b, 4) if a != "kernel_cycles" else round(b)) for a, b in out.items()}
     except Exception:
         return None
 
@@ -79,6 +128,17 @@ def parse():
                     help="ghost cell planes per slab side for N>1; 0 = time 4 (one halo refresh per sub-step) and "
                          "2 (three, half the ghost particles) on this machine's links before the run and keep "
                          "the faster; results are bit-identical either way")
+    ap.add_argument("--evolved-steps", type=int, default=2000,
+                    help="N=1: after the BASELINE window, carry the same scene on until it has taken this many "
+                         "sub-steps (the collapsing dam break) and time it again -> `evolved` (0 = skip)")
+    ap.add_argument("--no-shuffle", action="store_true",
+                    help="upload the block in generation order (x-major, z-fastest = already cell-sorted) instead "
+                         "of a fixed random permutation")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N>1: skip the secondary records (BASELINE's 16 M strong-scaling scene and the "
+                         "8 M-per-GPU XSPH + vorticity weak-scaling scene)")
+    ap.add_argument("--extras-strong-block", type=int, nargs=3, default=[256, 250, 250])
+    ap.add_argument("--extras-weak-block", type=int, nargs=3, default=[200, 200, 200])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with several ranks sharing one GPU "
                          "(payloads staged through the host); numbers from it are not bench results")
@@ -130,6 +190,116 @@ def cpu_baseline(block, iters, steps):
     }
 
 
+def shuffled(pos, enabled=True):
+    """The generators emit the block x-major / z-fastest, which IS the cell-sorted order: uploaded
+    like that the first counting sort would be a no-op and every particle's id would equal its
+    sorted rank.  A fixed permutation removes that best case (ids, hence the order inside a cell,
+    are then unrelated to position); the physics does not depend on it."""
+    if not enabled:
+        return pos, "generation order (already cell-sorted)"
+    import numpy as np
+    perm = np.random.default_rng(20240611).permutation(pos.shape[0])
+    return np.ascontiguousarray(pos[perm]), "fixed random permutation (seed 20240611)"
+
+
+def phase_table(ctx, stepper, barrier, ksteps):
+    """per-kernel device time with HIP events on the ctx stream (the event records sit between
+    launches, so such a pass is never the one a `value` comes from)"""
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(ksteps):
+        stepper(DT)
+    barrier()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    return {name: {"ms_per_launch": ms / calls, "launches_per_step": calls / ksteps, "ms_per_step": ms / ksteps}
+            for name, (ms, calls) in prof.items() if calls}
+
+
+def multi_gpu_extras(a, sim, rank, world, local, time_steps):
+    """Inside a --gpus N launch: BASELINE.json's two multi-GPU configurations, each next to the same
+    work on ONE GPU (rank 0 alone, one ctx), so the line carries measured efficiencies.
+      strong_16m   : the 256x250x250 = 16 M-particle scene as N x-slabs (C4, strong scaling)
+      weak_8m_visc : one 200^3 = 8 M-particle block per GPU with XSPH + vorticity (C5, weak scaling)
+    Sizes follow --extras-strong-block / --extras-weak-block (the CPU-side rehearsal shrinks them)."""
+    import torch
+    import torch.distributed as dist
+    from fluidsimulation_amd import PbfContext, scenes
+    from fluidsimulation_amd.slab import SlabSimulation
+    shared = getattr(sim.group.exchange, "comm", None)
+    dev = "cuda" if a.backend == "nccl" else "cpu"
+    layers = sim.ghost_layers
+    warm, k = 5, 10
+
+    def one_gpu(p, pos, mass, cols):
+        """ms per sub-step of one ctx on rank 0's GPU, told to every rank"""
+        t = torch.zeros(1, dtype=torch.float64, device=dev)
+        if rank == 0:
+            g = PbfContext(p, device=local)
+            g.upload(pos, uniform_mass=mass)
+            g.set_colliders(cols)
+            for _ in range(warm):
+                g.step(DT)
+            g.sync()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                g.step(DT)
+            g.sync()
+            t[0] = (time.perf_counter() - t0) / k
+            g.close()
+            torch.cuda.empty_cache()
+        dist.broadcast(t, 0)
+        return float(t.item())
+
+    def as_slabs(p, pos, mass, cols):
+        s = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=layers,
+                           comm=shared, transport="torch" if shared is None else "auto")
+        for _ in range(warm):
+            s.step(DT)
+        t = time_steps(s.step, s.sync, k)
+        st = s.stats()
+        owned = s.owned_counts()
+        s.sync()
+        del s
+        torch.cuda.empty_cache()
+        return t, st, owned
+
+    out = {}
+    # C4: strong scaling of ONE 16 M-particle scene
+    nx, ny, nz = a.extras_strong_block
+    p, pos, mass, cols = scenes.dam_break(nx, ny, nz, iterations=a.iters)
+    pos, _ = shuffled(pos, not a.no_shuffle)
+    n = pos.shape[0]
+    t1 = one_gpu(p, pos, mass, cols)
+    tn, st, owned = as_slabs(p, pos, mass, cols)
+    out["strong_16m"] = {"workload": f"{nx}x{ny}x{nz} dam-break block ({n} particles), {a.iters} iterations, "
+                                     f"{world} x-slabs, {layers} ghost layers", "scaling": "strong",
+                         "ms_per_step_1gpu": t1 * 1e3, "ms_per_step": tn * 1e3,
+                         "value": n / tn, "value_1gpu": n / t1, "parallel_efficiency": t1 / (world * tn),
+                         "owned_per_rank": owned, "nonfinite": st["nonfinite"],
+                         "neighbor_overflow": st["neighbor_overflow"], "steps": k, "warmup": warm}
+    del pos
+    # C5: weak scaling, one 8 M-particle block per GPU, viscosity stages on
+    bx, by, bz = a.extras_weak_block
+    xs, vo = 0.01, 2e-6
+    p1, pos1, mass, cols1 = scenes.dam_break(bx, by, bz, iterations=a.iters, xsph_c=xs, vorticity_eps=vo)
+    pos1, _ = shuffled(pos1, not a.no_shuffle)
+    t1 = one_gpu(p1, pos1, mass, cols1)
+    n1 = pos1.shape[0]
+    del pos1
+    p, pos, mass, cols = scenes.dam_break(bx * world, by, bz, iterations=a.iters, xsph_c=xs, vorticity_eps=vo)
+    pos, _ = shuffled(pos, not a.no_shuffle)
+    n = pos.shape[0]
+    tn, st, owned = as_slabs(p, pos, mass, cols)
+    out["weak_8m_visc"] = {"workload": f"{bx}x{by}x{bz} block per GPU ({n1} particles each, {n} in all), {a.iters} "
+                                       f"iterations, XSPH {xs} + vorticity {vo}, {world} x-slabs, {layers} ghost layers",
+                           "scaling": "weak", "ms_per_step_1gpu_one_block": t1 * 1e3, "ms_per_step": tn * 1e3,
+                           "value": n / tn, "value_1gpu_one_block": n1 / t1, "parallel_efficiency": t1 / tn,
+                           "owned_per_rank": owned, "nonfinite": st["nonfinite"],
+                           "neighbor_overflow": st["neighbor_overflow"], "steps": k, "warmup": warm}
+    return out
+
+
 def main():
     a = parse()
     import torch
@@ -155,6 +325,7 @@ def main():
 
     if world == 1:
         p, pos, mass, cols = scenes.dam_break(*block, iterations=a.iters, xsph_c=a.xsph, vorticity_eps=a.vorticity)
+        pos, upload_order = shuffled(pos, not a.no_shuffle)
         ctx = PbfContext(p, device=local)
         ctx.upload(pos, uniform_mass=mass)
         ctx.set_colliders(cols)
@@ -169,6 +340,7 @@ def main():
         scene_nx = block[0] if a.strong else block[0] * world
         p, pos, mass, cols = scenes.dam_break(scene_nx, block[1], block[2], iterations=a.iters, xsph_c=a.xsph,
                                               vorticity_eps=a.vorticity)
+        pos, upload_order = shuffled(pos, not a.no_shuffle)
         # ghost_layers = 4: one halo refresh per sub-step instead of three (slab.py, "communication-
         # avoiding halo"); transport: grouped ncclSend/ncclRecv from the C-ABI library when the
         # group runs on nccl (torch.distributed stays the bootstrap and the fallback)
@@ -241,20 +413,11 @@ def main():
     # records sit between launches, so this pass is not the one `value` comes from)
     roofline = None
     phases = {}
+    pmc, pmc_note = load_pmc()
     if not a.no_profile:
-        ctx.profile_enable(True)
-        ctx.profile_reset()
         ksteps = max(1, min(a.steps, 50))
-        for _ in range(ksteps):
-            stepper(DT)
-        barrier()
-        prof = ctx.profile_read()
-        ctx.profile_enable(False)
+        phases = phase_table(ctx, stepper, barrier, ksteps)
         n_local = ctx.n
-        for name, (ms, calls) in prof.items():
-            if calls:
-                phases[name] = {"ms_per_launch": ms / calls, "launches_per_step": calls / ksteps,
-                                "ms_per_step": ms / ksteps}
         algo = dict(ALGO_BYTES)
         if "finalize" not in phases and "delta" in phases:
             # the velocity update rides along with the last delta-p launch of a sub-step (k_delta<FINAL>):
@@ -265,17 +428,56 @@ def main():
             dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
             per_launch_s = cand[dom]["ms_per_launch"] * 1e-3
             achieved = algo[dom] * n_local / per_launch_s / 1e9
-            tr = pmc_traffic(dom, a.iters)
-            traffic = None
+            traffic, limiters, achieved_hbm = None, None, None
             # the PMC summary derives its particle count from SQ_WAVES x 64 (rounded up per block)
-            if tr and abs(tr["particles_per_launch"] - n_local) < 1024:
-                traffic = tr["bytes_per_launch"]
+            if pmc and abs((pmc.get("particles_per_launch") or 0) - n_local) < 1024:
+                tr = pmc_traffic(pmc, dom, a.iters)
+                traffic = tr["bytes_per_launch"] if tr else None
+                limiters = {k: pmc_limiters(pmc, k) for k in ("lambda", "delta", "neighbors")}
+                achieved_hbm = traffic / per_launch_s / 1e9 if traffic else None
+            elif pmc:
+                pmc_note = "profiles/pmc_latest.json profiled another particle count: counters not quoted"
+            busiest = None
+            if limiters and limiters.get(dom):
+                lim = {k: v for k, v in limiters[dom].items() if k in ("valu", "l1", "lds", "hbm")}
+                busiest = max(lim, key=lim.get)
+            # `bound` names the roofline `achieved` / `peak` / `frac` are priced against (HBM;
+            # the path has no MFMA work).  What the counters say actually limits the kernel is `limited_by`.
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                        "achieved_is": "algorithmic bytes (SURVEY.md 8(d)) / measured launch time",
+                        "achieved_hbm_gbs": achieved_hbm,
+                        "limited_by": busiest, "limiters": limiters, "pmc_note": pmc_note,
                         "algorithmic_bytes_per_launch": algo[dom] * n_local,
                         "algorithmic_bytes_per_particle": algo[dom],
                         "avg_launch_ms": cand[dom]["ms_per_launch"], "particles_per_launch": n_local}
+
+    # the same scene once it is no lattice at rest any more (N = 1): `value` above is the BASELINE
+    # window (sub-steps warmup .. warmup + steps of the block at rest, ~20 neighbours per particle)
+    evolved = None
+    if world == 1 and a.evolved_steps > 0:
+        done = a.warmup + a.steps + (0 if a.no_profile else max(1, min(a.steps, 50)))
+        for _ in range(max(0, a.evolved_steps - done)):
+            stepper(DT)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            stepper(DT)
+        barrier()
+        t_ev = time.perf_counter() - t0
+        st = ctx.stats().as_dict()
+        evolved = {"after_substeps": max(done, a.evolved_steps), "steps": a.steps, "ms_per_step": t_ev / a.steps * 1e3,
+                   "value": n_total * a.steps / t_ev, "mean_neighbors": st["mean_neighbor_count"],
+                   "max_neighbors": st["max_neighbor_count"], "mean_abs_C": st["mean_abs_C"],
+                   "max_speed": st["max_speed"], "nonfinite": st["nonfinite"],
+                   "neighbor_overflow": st["neighbor_overflow"],
+                   "phases": None if a.no_profile else phase_table(ctx, stepper, barrier, max(1, min(a.steps, 50)))}
+
+    # N > 1: the two multi-GPU configurations BASELINE.json names, measured inside the same launch
+    extras = None
+    if world > 1 and not a.no_extras:
+        extras = multi_gpu_extras(a, sim, rank, world, local, time_steps)
 
     if rank == 0:
         value = n_total * a.steps / elapsed
@@ -297,12 +499,15 @@ def main():
             "dtype": "f32",
             "data": "synthetic" if a.backend == "nccl" else "synthetic (REHEARSAL over gloo: not a bench result)",
             "config": {"workload": workload + (f", XSPH {a.xsph} + vorticity {a.vorticity}" if (a.xsph or a.vorticity) else ""),
-                       "particles": n_total, "iterations": a.iters,
+                       "particles": n_total, "iterations": a.iters, "upload_order": upload_order,
+                       "timed_window": f"sub-steps {a.warmup}..{a.warmup + a.steps} from the block at rest",
                        "arithmetic": "f32 state and accumulation, f64 SPH-kernel evaluation (as the reference CPU path)", "parallelism": parallelism,
                        "substeps_per_s": a.steps / elapsed},
             "hbm_roofline_frac_substep": (290 - 2 * ALGO_BYTES_PER_ITER + a.iters * ALGO_BYTES_PER_ITER) * value / (HBM_PEAK_GBS * 1e9 * world),
             "roofline": roofline,
             "phases": phases,
+            "evolved": evolved,
+            "extras": extras,
             "cpu_baseline": cpu,
             "health": {"nonfinite": stats["nonfinite"], "neighbor_overflow": stats["neighbor_overflow"],
                        "max_neighbors": stats["max_neighbor_count"],

@@ -13,7 +13,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def test_bench_prints_one_json_line_with_the_contract_keys():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "5", "--warmup", "2", "--block", "24", "24",
-                        "24", "--cpu-steps", "2"], capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+                        "24", "--cpu-steps", "2", "--evolved-steps", "60"], capture_output=True, text=True, timeout=300, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
@@ -34,6 +34,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert cb["unit"] == d["unit"] and "sample" in cb
     assert d["health"]["nonfinite"] == 0 and d["health"]["neighbor_overflow"] == 0
+    assert "achieved_hbm_gbs" in rf and "limited_by" in rf and "limiters" in rf
+    assert "permutation" in d["config"]["upload_order"]
+    ev = d["evolved"]
+    assert ev["after_substeps"] >= 60 and ev["ms_per_step"] > 0 and ev["nonfinite"] == 0
+    assert ev["neighbor_overflow"] == 0 and ev["mean_neighbors"] > 5 and "lambda" in ev["phases"]
 
 
 def test_bench_two_ranks_rehearsal_over_gloo():
@@ -45,7 +50,8 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
                         "--gpus", "2", "--steps", "4", "--warmup", "2", "--block", "24", "20", "20",
-                        "--backend", "gloo"], capture_output=True, text=True, timeout=400, cwd=str(ROOT))
+                        "--backend", "gloo", "--extras-strong-block", "30", "16", "16", "--extras-weak-block", "16",
+                        "16", "16"], capture_output=True, text=True, timeout=400, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -54,4 +60,13 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     assert d["config"]["particles"] == 2 * 24 * 20 * 20
     assert "slab2" in d["config"]["parallelism"] and "picked from" in d["config"]["parallelism"]
     assert "REHEARSAL" in d["data"]
+    # the secondary records of a multi-GPU launch: BASELINE's strong (C4) and viscous weak (C5) scenes,
+    # here at rehearsal sizes, each with its one-GPU reference time and an efficiency
+    ex = d["extras"]
+    assert ex["strong_16m"]["scaling"] == "strong" and ex["weak_8m_visc"]["scaling"] == "weak"
+    for rec in ex.values():
+        assert rec["ms_per_step"] > 0 and rec["parallel_efficiency"] > 0 and rec["nonfinite"] == 0
+        assert rec["neighbor_overflow"] == 0 and len(rec["owned_per_rank"]) == 2
+    assert sum(ex["strong_16m"]["owned_per_rank"]) == 30 * 16 * 16
+    assert sum(ex["weak_8m_visc"]["owned_per_rank"]) == 2 * 16 ** 3
     assert d["health"]["nonfinite"] == 0 and d["health"]["neighbor_overflow"] == 0

@@ -8,7 +8,7 @@ OUT=${1:-gpurun_out/pmc}
 ROOT=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 4 --warmup 2 --cpu-steps 0 --no-profile"
+BENCH="python3 $ROOT/bench.py --steps 4 --warmup 2 --cpu-steps 0 --no-profile --evolved-steps 0"
 run_pass() {
   name=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -- $BENCH \

@@ -4,8 +4,13 @@ report for profiles/.  Usage: summarize_prof.py <pmc_dir> [<kernel_stats.csv>] >
 import csv
 import glob
 import json
+import subprocess
 import sys
 from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
 
 
 def short(name):
@@ -31,7 +36,14 @@ def main():
         if ref in out and "SQ_WAVES" in out[ref]:
             n = int(round(out[ref]["SQ_WAVES"] * 64))
             break
+    from bench import kernel_source_sha     # the fingerprint bench.py checks before it quotes these counters
+    try:
+        head = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True,
+                              text=True).stdout.strip() or None
+    except OSError:
+        head = None
     print(json.dumps({"particles_per_launch": n, "units": "per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB",
+                      "kernel_source_sha": kernel_source_sha(), "git_head_when_summarised": head,
                       "kernels": out}, indent=1, sort_keys=True))
 
 

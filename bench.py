@@ -231,38 +231,59 @@ def multi_gpu_extras(a, sim, rank, world, local, time_steps):
     layers = sim.ghost_layers
     warm, k = 5, 10
 
+    def agree(ok):
+        """every rank learns whether all ranks got through the last rank-local stage (allocation,
+        scene set-up): a rank that failed must not leave the others inside a collective"""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
     def one_gpu(p, pos, mass, cols):
-        """ms per sub-step of one ctx on rank 0's GPU, told to every rank"""
-        t = torch.zeros(1, dtype=torch.float64, device=dev)
+        """ms per sub-step of one ctx on rank 0's GPU, told to every rank (None: it did not fit / failed)"""
+        t = torch.full((1,), -1.0, dtype=torch.float64, device=dev)
         if rank == 0:
-            g = PbfContext(p, device=local)
-            g.upload(pos, uniform_mass=mass)
-            g.set_colliders(cols)
-            for _ in range(warm):
-                g.step(DT)
-            g.sync()
-            t0 = time.perf_counter()
-            for _ in range(k):
-                g.step(DT)
-            g.sync()
-            t[0] = (time.perf_counter() - t0) / k
-            g.close()
+            try:
+                g = PbfContext(p, device=local)
+                g.upload(pos, uniform_mass=mass)
+                g.set_colliders(cols)
+                for _ in range(warm):
+                    g.step(DT)
+                g.sync()
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    g.step(DT)
+                g.sync()
+                t[0] = (time.perf_counter() - t0) / k
+                g.close()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench extras] one-GPU reference failed: {e}", file=sys.stderr)
             torch.cuda.empty_cache()
         dist.broadcast(t, 0)
-        return float(t.item())
+        v = float(t.item())
+        return v if v > 0 else None
 
     def as_slabs(p, pos, mass, cols):
-        s = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=layers,
-                           comm=shared, transport="torch" if shared is None else "auto")
-        for _ in range(warm):
-            s.step(DT)
-        t = time_steps(s.step, s.sync, k)
-        st = s.stats()
-        owned = s.owned_counts()
-        s.sync()
-        del s
-        torch.cuda.empty_cache()
-        return t, st, owned
+        s, err = None, None
+        try:
+            s = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=layers,
+                               comm=shared, transport="torch" if shared is None else "auto")
+        except Exception as e:  # noqa: BLE001  (rank-local: allocation, capacity)
+            err = f"rank {rank}: {e}"
+        if not agree(err is None):
+            return None, err or "another rank could not set up its slab"
+        try:   # pbf_slab_step fails collectively (every rank raises the same error in the same sub-step)
+            for _ in range(warm):
+                s.step(DT)
+            t = time_steps(s.step, s.sync, k)
+            st = s.stats()
+            owned = s.owned_counts()
+            s.sync()
+        except Exception as e:  # noqa: BLE001
+            return None, str(e)
+        finally:
+            del s
+            torch.cuda.empty_cache()
+        return (t, st, owned), None
 
     out = {}
     # C4: strong scaling of ONE 16 M-particle scene
@@ -271,13 +292,18 @@ def multi_gpu_extras(a, sim, rank, world, local, time_steps):
     pos, _ = shuffled(pos, not a.no_shuffle)
     n = pos.shape[0]
     t1 = one_gpu(p, pos, mass, cols)
-    tn, st, owned = as_slabs(p, pos, mass, cols)
-    out["strong_16m"] = {"workload": f"{nx}x{ny}x{nz} dam-break block ({n} particles), {a.iters} iterations, "
-                                     f"{world} x-slabs, {layers} ghost layers", "scaling": "strong",
-                         "ms_per_step_1gpu": t1 * 1e3, "ms_per_step": tn * 1e3,
-                         "value": n / tn, "value_1gpu": n / t1, "parallel_efficiency": t1 / (world * tn),
-                         "owned_per_rank": owned, "nonfinite": st["nonfinite"],
-                         "neighbor_overflow": st["neighbor_overflow"], "steps": k, "warmup": warm}
+    res, err = as_slabs(p, pos, mass, cols)
+    rec = {"workload": f"{nx}x{ny}x{nz} dam-break block ({n} particles), {a.iters} iterations, {world} x-slabs, "
+                       f"{layers} ghost layers", "scaling": "strong", "steps": k, "warmup": warm,
+           "ms_per_step_1gpu": None if t1 is None else t1 * 1e3, "value_1gpu": None if t1 is None else n / t1}
+    if res:
+        tn, st, owned = res
+        rec.update({"ms_per_step": tn * 1e3, "value": n / tn,
+                    "parallel_efficiency": None if t1 is None else t1 / (world * tn), "owned_per_rank": owned,
+                    "nonfinite": st["nonfinite"], "neighbor_overflow": st["neighbor_overflow"]})
+    else:
+        rec["error"] = err
+    out["strong_16m"] = rec
     del pos
     # C5: weak scaling, one 8 M-particle block per GPU, viscosity stages on
     bx, by, bz = a.extras_weak_block
@@ -290,13 +316,19 @@ def multi_gpu_extras(a, sim, rank, world, local, time_steps):
     p, pos, mass, cols = scenes.dam_break(bx * world, by, bz, iterations=a.iters, xsph_c=xs, vorticity_eps=vo)
     pos, _ = shuffled(pos, not a.no_shuffle)
     n = pos.shape[0]
-    tn, st, owned = as_slabs(p, pos, mass, cols)
-    out["weak_8m_visc"] = {"workload": f"{bx}x{by}x{bz} block per GPU ({n1} particles each, {n} in all), {a.iters} "
-                                       f"iterations, XSPH {xs} + vorticity {vo}, {world} x-slabs, {layers} ghost layers",
-                           "scaling": "weak", "ms_per_step_1gpu_one_block": t1 * 1e3, "ms_per_step": tn * 1e3,
-                           "value": n / tn, "value_1gpu_one_block": n1 / t1, "parallel_efficiency": t1 / tn,
-                           "owned_per_rank": owned, "nonfinite": st["nonfinite"],
-                           "neighbor_overflow": st["neighbor_overflow"], "steps": k, "warmup": warm}
+    res, err = as_slabs(p, pos, mass, cols)
+    rec = {"workload": f"{bx}x{by}x{bz} block per GPU ({n1} particles each, {n} in all), {a.iters} iterations, "
+                       f"XSPH {xs} + vorticity {vo}, {world} x-slabs, {layers} ghost layers", "scaling": "weak",
+           "steps": k, "warmup": warm, "ms_per_step_1gpu_one_block": None if t1 is None else t1 * 1e3,
+           "value_1gpu_one_block": None if t1 is None else n1 / t1}
+    if res:
+        tn, st, owned = res
+        rec.update({"ms_per_step": tn * 1e3, "value": n / tn,
+                    "parallel_efficiency": None if t1 is None else t1 / tn, "owned_per_rank": owned,
+                    "nonfinite": st["nonfinite"], "neighbor_overflow": st["neighbor_overflow"]})
+    else:
+        rec["error"] = err
+    out["weak_8m_visc"] = rec
     return out
 
 

@@ -201,7 +201,7 @@ SYMBOLS = [
     "pbf_comm_last_error", "pbf_comm_batch", "pbf_slab_halo_exchange", "pbf_step_dem",
     "pbf_set_distance_constraints", "pbf_project_constraints", "pbf_get_constraint_lambdas",
     "pbf_comm_local_id", "pbf_slab_attach", "pbf_slab_step", "pbf_slab_owned_count",
-    "pbf_slab_append_owned_host", "pbf_slab_export_host", "pbf_build_cells_noalloc",
+    "pbf_slab_append_owned_host", "pbf_slab_export_host", "pbf_build_cells_noalloc", "pbf_slab_rebalance",
 ]
 
 _lib = None
@@ -285,6 +285,8 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_slab_attach.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32]
     lib.pbf_slab_step.argtypes = [vp, C.c_float]
     lib.pbf_slab_owned_count.argtypes = [vp]
+    lib.pbf_slab_rebalance.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.c_int32,
+                                       C.POINTER(C.c_int32)]
     lib.pbf_slab_owned_count.restype = C.c_uint32
     lib.pbf_comm_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.pbf_comm_destroy.argtypes = [vp]
@@ -597,6 +599,14 @@ class PbfContext:
     def slab_step(self, dt):
         self._ck(self.lib.pbf_slab_step(self._h, C.c_float(dt)))
         self.n = int(self.lib.pbf_num_particles(self._h))
+
+    def slab_rebalance(self, planes, x_first: int, n_planes: int, max_move: int):
+        """collective; returns (new planes, number of planes moved)"""
+        arr = (C.c_int32 * len(planes))(*[int(v) for v in planes])
+        moved = C.c_int32()
+        self._ck(self.lib.pbf_slab_rebalance(self._h, arr, int(x_first), int(n_planes), int(max_move),
+                                             C.byref(moved)))
+        return [int(v) for v in arr], int(moved.value)
 
     def slab_owned_count(self) -> int:
         return int(self.lib.pbf_slab_owned_count(self._h))

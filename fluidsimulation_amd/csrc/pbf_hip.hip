@@ -139,6 +139,8 @@ struct pbf_ctx {
     float4 *x_hsend[2] = {nullptr, nullptr}, *x_hrecv[2] = {nullptr, nullptr};
     uint32_t *x_counts = nullptr;       // device: (1 + world) counter blocks of XC_WORDS: own, then every rank's
     uint32_t *x_host_counts = nullptr;  // pinned host mirror of the same size
+    uint32_t *x_hist = nullptr, *x_host_hist = nullptr;   // re-balancing: (1 + world) plane histograms
+    uint32_t x_hist_planes = 0;
     bool owns_stream = true;
     bool uniform = false;      // every particle has uniform_mass (no per-neighbour mass gather)
     float uniform_mass = 0.f;
@@ -386,6 +388,10 @@ void free_link(pbf_ctx* c) {
     (void)hipFree(c->x_counts);
     if (c->x_host_counts) (void)hipHostFree(c->x_host_counts);
     c->x_counts = c->x_host_counts = nullptr;
+    (void)hipFree(c->x_hist);
+    if (c->x_host_hist) (void)hipHostFree(c->x_host_hist);
+    c->x_hist = c->x_host_hist = nullptr;
+    c->x_hist_planes = 0;
     c->link_comm = nullptr;
     c->link_max = 0;
 }

@@ -83,6 +83,25 @@ inline pbf_params rank_local_params(const pbf_params& P, const std::vector<Vec3>
     return p;
 }
 
+// the global cell planes pbf_slab_rebalance histograms over: the tank when the scene has one, else
+// the initial block with a margin of 64 cells (at most 4096 planes)
+inline void plane_range(const pbf_params& P, const std::vector<Vec3>& pos, int32_t* x_first, uint32_t* n_planes) {
+    int32_t lo = INT32_MAX, hi = INT32_MIN;
+    if (P.container_enabled) {
+        lo = (int32_t)std::floor(P.container_min[0] / P.grid_spacing);
+        hi = (int32_t)std::floor(std::min(P.container_max[0], 1e30f) / P.grid_spacing) + 1;
+    } else {
+        for (const Vec3& q : pos) {
+            const int32_t c = cell_x(q.x, P.grid_spacing);
+            lo = std::min(lo, c - 64);
+            hi = std::max(hi, c + 65);
+        }
+        if (pos.empty()) lo = 0, hi = 1;
+    }
+    *x_first = lo;
+    *n_planes = (uint32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)hi - lo, 4096));
+}
+
 // particle records (include/pbf.h: PBF_RECORD_FLOATS) of the particles whose cell x lies in
 // [x_lo, x_hi): pos.xyz, mass, vel.xyz, id bits, pred.xyz, 0
 inline std::vector<float> records_in(const std::vector<Vec3>& pos, float mass, float spacing,

@@ -4,7 +4,7 @@
 // (fluidsimulation_amd/scenes.py::dam_break restated).
 //
 //   pbf_slab_run --dims nx ny nz [--steps N] [--iters K] [--ghost-layers L]
-//       --slabs W [--check]           W rank THREADS of this process over the library's loopback
+//       --slabs W [--check] [--rebalance K]          W rank THREADS of this process over the library's loopback
 //                                     transport, all on device 0 (what a one-GPU box can run);
 //                                     --check steps ONE ctx over the whole scene as well and
 //                                     compares bit for bit
@@ -85,11 +85,13 @@ struct RankResult {
     std::vector<float> records;   // owned particles at the end
     std::string error;
     double seconds = 0;
+    int planes_moved = 0;
 };
 
 // one rank: its slab of the scene, stepped natively
-void run_rank(const Scene& sc, const std::vector<int32_t>& planes, int rank, int world, int device,
-              int layers, int steps, float dt, const void* comm_id, RankResult* out) {
+void run_rank(const Scene& sc, const std::vector<int32_t>& planes0, int rank, int world, int device,
+              int layers, int steps, float dt, const void* comm_id, RankResult* out, int rebalance_every = 0) {
+    std::vector<int32_t> planes = planes0;   // this rank's copy: pbf_slab_rebalance keeps all copies equal
     pbf_ctx* ctx = nullptr;
     pbf_comm* comm = nullptr;
     auto fail = [&](const char* what) {
@@ -115,8 +117,19 @@ void run_rank(const Scene& sc, const std::vector<int32_t>& planes, int rank, int
     if (pbf_slab_attach(ctx, comm, rank == 0 ? -1 : rank - 1, rank == world - 1 ? -1 : rank + 1, 0) != PBF_OK)
         return fail("pbf_slab_attach");
     auto t0 = std::chrono::steady_clock::now();
-    for (int s = 0; s < steps; ++s)
+    // re-balancing histograms cover the tank's cell planes (SlabDriver.h: plane_range)
+    int32_t x_first = 0;
+    uint32_t n_planes = 1;
+    slab::plane_range(sc.P, sc.pos, &x_first, &n_planes);
+    for (int s = 0; s < steps; ++s) {
         if (pbf_slab_step(ctx, dt) != PBF_OK) return fail("pbf_slab_step");
+        if (rebalance_every > 0 && layers >= 2 && world > 1 && (s + 1) % rebalance_every == 0) {
+            int32_t moved = 0;
+            if (pbf_slab_rebalance(ctx, planes.data(), x_first, n_planes, layers - 1, &moved) != PBF_OK)
+                return fail("pbf_slab_rebalance");
+            out->planes_moved += moved;
+        }
+    }
     if (pbf_sync(ctx) != PBF_OK) return fail("pbf_sync");
     out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     uint32_t k = 0;
@@ -132,6 +145,7 @@ void run_rank(const Scene& sc, const std::vector<int32_t>& planes, int rank, int
 int main(int argc, char** argv) {
     int nx = 48, ny = 12, nz = 12, steps = 5, iters = 4, slabs = 0, layers = 4, rank = -1, world = 0, device = -1;
     bool check = false;
+    int rebalance = 0;   // --rebalance K: pbf_slab_rebalance every K sub-steps
     std::string id_file;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -145,6 +159,7 @@ int main(int argc, char** argv) {
         else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
         else if (a == "--id-file" && i + 1 < argc) id_file = argv[++i];
         else if (a == "--check") check = true;
+        else if (a == "--rebalance" && i + 1 < argc) rebalance = atoi(argv[++i]);
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     const float dt = 0.0005f;  // GLFWApp.cpp:393
@@ -170,7 +185,7 @@ int main(int argc, char** argv) {
         }
         const std::vector<int32_t> planes = slab::split_planes(sc.pos, sc.P.grid_spacing, world, 2 * layers + 1);
         RankResult res;
-        run_rank(sc, planes, rank, world, device < 0 ? rank : device, layers, steps, dt, id, &res);
+        run_rank(sc, planes, rank, world, device < 0 ? rank : device, layers, steps, dt, id, &res, rebalance);
         if (!res.error.empty()) { fprintf(stderr, "rank %d: %s\n", rank, res.error.c_str()); return 1; }
         printf("rank %d of %d: %zu owned particles after %d sub-steps, %.3f ms/sub-step\n", rank, world,
                res.records.size() / PBF_RECORD_FLOATS, steps, 1e3 * res.seconds / (steps > 0 ? steps : 1));
@@ -185,7 +200,7 @@ int main(int argc, char** argv) {
     std::vector<std::thread> th;
     for (int r = 0; r < slabs; ++r)
         th.emplace_back(run_rank, std::cref(sc), std::cref(planes), r, slabs, device < 0 ? 0 : device, layers, steps,
-                        dt, (const void*)id, &res[(size_t)r]);
+                        dt, (const void*)id, &res[(size_t)r], rebalance);
     for (auto& t : th) t.join();
     size_t total = 0;
     double slowest = 0;
@@ -196,6 +211,11 @@ int main(int argc, char** argv) {
     }
     printf("particles %zu in %d slabs (%d ghost layers), %d sub-steps, %d iterations: %.3f ms/sub-step (slowest rank)\n",
            n, slabs, layers, steps, iters, 1e3 * slowest / (steps > 0 ? steps : 1));
+    if (rebalance > 0) {
+        printf("re-balanced every %d sub-steps: %d plane moves; owned per rank at the end:", rebalance, res[0].planes_moved);
+        for (int r = 0; r < slabs; ++r) printf(" %zu", res[(size_t)r].records.size() / PBF_RECORD_FLOATS);
+        printf("\n");
+    }
     if (total != n) { fprintf(stderr, "particle count changed: %zu -> %zu\n", n, total); return 1; }
     if (check) {
         // ONE ctx over the whole scene, same steps; compare position and velocity by particle id

@@ -597,6 +597,14 @@ class SlabSimulation:
                                          -1 if rank == world - 1 else rank + 1, self.backend.max_records)
             self.transport = "rccl (C ABI, native sub-step)"
         self.ctx = self.backend.ctx
+        # global cell planes the re-balancing histograms cover: the tank, or the initial block +- 64
+        if params.container_enabled:
+            lo = int(np.floor(params.container_min[0] / params.grid_spacing))
+            hi = int(np.floor(min(params.container_max[0], 1e30) / params.grid_spacing)) + 1
+        else:
+            cx = cell_x(pos[:, 0], params.grid_spacing)
+            lo, hi = int(cx.min()) - 64, int(cx.max()) + 65
+        self.x_first, self.n_planes = lo, max(1, min(hi - lo, 4096))
         self.dist = dist
         self.rank, self.world = rank, world
         self.steps = 0
@@ -621,7 +629,17 @@ class SlabSimulation:
         return [int(t.item()) for t in out]
 
     def rebalance(self, tolerance=0.05):
-        self.planes = self.group.rebalance(self.planes, self.owned_counts(), tolerance)
+        """native path: pbf_slab_rebalance (plane histograms gathered over the C-ABI transport, every
+        interior plane moved up to ghost_layers - 1 cells towards the equal-count split); otherwise
+        one cell per call from the owned counts (SlabGroup.rebalance)"""
+        if self.native and self.ghost_layers >= 2:
+            self.planes, moved = self.ctx.slab_rebalance(self.planes, self.x_first, self.n_planes,
+                                                         self.ghost_layers - 1)
+            return moved
+        new = self.group.rebalance(self.planes, self.owned_counts(), tolerance)
+        moved = sum(1 for a, b in zip(new, self.planes) if a != b)
+        self.planes = new
+        return moved
 
     def stats(self):
         """Whole-scene health figures: the per-rank pbf_get_stats (owned particles only) combined

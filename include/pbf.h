@@ -393,6 +393,17 @@ int pbf_slab_export_host(pbf_ctx* ctx, float* records, uint32_t max_records, uin
 int pbf_slab_attach(pbf_ctx* ctx, pbf_comm* comm, int32_t left_rank, int32_t right_rank,
                     uint32_t max_records);
 int pbf_slab_step(pbf_ctx* ctx, float dt);
+/* Collective re-balancing between sub-steps (every rank of the communicator calls it with the same
+ * arguments): the per-x-plane counts of the owned particles of all ranks are gathered on every rank
+ * (cell planes [x_first, x_first + n_planes), n_planes <= 4096; particles outside count in the end
+ * bins), every rank computes the same equal-count planes and moves each interior plane towards its
+ * target by at most max_move cells (1 <= max_move <= ghost_layers - 1: the particles of a moved
+ * plane travel as ordinary migrants of the next sub-step), keeping interior slabs at least
+ * 2 * ghost_layers planes wide.  planes[world + 1] (planes[0] = INT32_MIN, planes[world] =
+ * INT32_MAX) is updated in place, identically on every rank, and this ctx's bounds follow
+ * (pbf_slab_set_bounds).  *moved = number of planes that changed.  Synchronises. */
+int pbf_slab_rebalance(pbf_ctx* ctx, int32_t* planes, int32_t x_first, uint32_t n_planes, int32_t max_move,
+                       int32_t* moved);
 /* owned particles after the last sub-step (its ghosts sit behind them until the next split) */
 uint32_t pbf_slab_owned_count(const pbf_ctx* ctx);
 

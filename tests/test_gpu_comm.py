@@ -491,3 +491,86 @@ def test_slab_bounds_reject_an_interior_slab_narrower_than_two_ghost_depths():
     g.slab_set_bounds(10, 14, 2)              # exactly 2 * ghost_layers: fine
     g.slab_set_bounds(-2**31, 12, 4)          # an open end lifts the rule
     g.slab_set_bounds(10, 2**31 - 1, 4)
+
+
+def test_native_rebalance_moves_planes_towards_equal_counts_and_keeps_the_result():
+    """pbf_slab_rebalance between sub-steps of a collapsing dam break cut deliberately unevenly
+    (rank 0 owns two thirds): the plane histograms of all ranks are gathered on every rank, every
+    rank moves the planes identically (up to ghost_layers - 1 cells per call), the owned counts
+    approach balance, and the state stays bit-identical with the single-domain oracle."""
+    import threading
+    from fluidsimulation_amd import slab as S
+    from oracle import pyoracle
+    from tests.slab_common import slab_scene
+    world, layers, steps = 3, 3, 12
+    p, pos, mass, cols, vel = slab_scene(nx=60, ny=6, nz=6, iterations=2)
+    even = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers)
+    planes = [even[0], even[1] + 6, even[2] + 5, even[3]]           # off balance
+    lo = int(np.floor(p.container_min[0] / p.grid_spacing))
+    n_planes = int(np.floor(p.container_max[0] / p.grid_spacing)) + 1 - lo
+    uid = RcclComm.local_id()
+    out, errs, hist = {}, [], {}
+
+    def rank_main(rank):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                q = S.rank_local_params(p, pos, planes, rank, world, headroom=3.0, ghost_layers=layers)
+                q.grid_dim[0] = p.grid_dim[0]          # room for the planes to travel
+                q.grid_origin_cell[0] = p.grid_origin_cell[0]
+                b = S.HipSlabBackend(q, cols, mass, planes[rank], planes[rank + 1], device=0, ghost_layers=layers)
+                S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
+                           p.grid_spacing, vel=vel)
+                comm = RcclComm(uid, rank, world, 0)
+                b.ctx.slab_attach(comm, -1 if rank == 0 else rank - 1, -1 if rank == world - 1 else rank + 1,
+                                  b.max_records)
+                mine, track = list(planes), []
+                for s in range(steps):
+                    b.ctx.slab_step(DT)
+                    if s % 2 == 1:
+                        mine, moved = b.ctx.slab_rebalance(mine, lo, n_planes, layers - 1)
+                        track.append((list(mine), moved, b.ctx.slab_owned_count()))
+                b.sync()
+                hist[rank] = track
+                out[rank] = b.export()
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs
+    # every rank took the same decisions; planes moved, never more than layers - 1 cells per call
+    assert [h[0] for h in hist[0]] == [h[0] for h in hist[1]] == [h[0] for h in hist[2]]
+    seq = [planes] + [h[0] for h in hist[0]]
+    assert seq[-1] != planes and sum(h[1] for h in hist[0]) > 0
+    for a, b in zip(seq, seq[1:]):
+        assert all(abs(x - y) <= layers - 1 for x, y in zip(a[1:-1], b[1:-1]))
+        assert b[2] - b[1] >= 2 * layers
+    first = [len(out[r]) for r in range(world)]
+    start = np.bincount(np.searchsorted(planes[1:-1], S.cell_x(pos[:, 0], p.grid_spacing), side="right"),
+                        minlength=world)
+    assert max(first) - min(first) < max(start) - min(start), (start, first)
+    rec = np.concatenate([out[r] for r in range(world)], axis=0)
+    order = np.argsort(S.record_ids(rec))
+    o = pyoracle.Oracle(p)
+    o.upload(pos, vel=vel, uniform_mass=mass)
+    o.set_colliders(cols)
+    for _ in range(steps):
+        o.step(DT)
+    op, ov, _, _ = o.download()
+    assert rec.shape[0] == pos.shape[0]
+    assert np.array_equal(rec[order, 0:3], op) and np.array_equal(rec[order, 4:7], ov)
+
+
+def test_native_rebalance_rejects_moves_the_migration_cannot_carry():
+    from fluidsimulation_amd import binding as B
+    p, pos, mass, cols = scenes.dam_break(8, 6, 6, iterations=2)
+    g = PbfContext(p, device=0)
+    g.slab_set_bounds(-2**31, 2**31 - 1, 2)
+    with pytest.raises(PbfError) as e:
+        g.slab_rebalance([-2**31, 2**31 - 1], 0, 16, 1)      # no communicator attached
+    assert e.value.code == B.PBF_ERR_INVALID

@@ -197,35 +197,69 @@ __device__ __forceinline__ float scorr_strict(const KernConsts& k, float w) {
 }
 
 // ---- neighbour table layout.  The table of a set with `cap` slots holds the k-th neighbour of
-// particle i at word k * cap + i (m_search_cache transposed: row k of every particle contiguous,
-// one coalesced 256-byte read per wave).  Rows are walked four at a time; the builder
+// particle i in row k (m_search_cache transposed: row k of every particle contiguous, one coalesced
+// read per wave); a row is cap 32-bit words.  Rows are walked four at a time; the builder
 // (k_neighbors) pads a particle's list to a multiple of four with a valid index, so a sweep loads
-// the four entries of a group without a per-entry predicate or dummy select, from a UNIFORM row
-// base (scalar registers) plus the lane's slot -- no per-entry vector address arithmetic -- and
-// the gathers of the masked-off tail never leave the target array.
+// the four entries of a group without a per-entry predicate or dummy select, from a UNIFORM row base
+// (scalar registers) plus the lane's offset, and the gathers of the masked-off tail never leave the
+// target array.
+// Entry format, per group of 256 consecutive slots (the builder's workgroup), flagged in bit 31 of
+// every count word of the group (NBR_REL16; the count is the low bits):
+//   0: the neighbour's sorted slot, 32 bits, at word i of the row;
+//   1: the slot RELATIVE to the particle's own, 16 bits signed, at halfword (i & 255) of the group's
+//      1 KiB segment of the row (bytes [1024 (i >> 8), +512): dense, so a wave reads 128 contiguous
+//      bytes instead of 256).  Particles are cell-sorted, so a neighbour is at most about one x-plane
+//      of cells away in slot order; the builder picks this format when its whole candidate window
+//      lies within +-32767 slots of every particle of the group.  The rows are the bulk of the
+//      sweeps' HBM traffic (4 B x 20 neighbours x 8 sweeps per particle and sub-step): halved.
+// Tables whose query and target sets differ (fluid <-> boundary) are always format 0.
 __host__ __device__ __forceinline__ uint32_t nbr_rows(uint32_t K) { return (K + 3u) & ~3u; }
+constexpr uint32_t NBR_GROUP_SHIFT = 8;   // 256 slots: one k_neighbors workgroup
+constexpr uint32_t NBR_REL16 = 0x80000000u;          // count word: the group's entries are 16-bit relative
+constexpr uint32_t NBR_COUNT_MASK = 0x7fffffffu;
 
-__device__ __forceinline__ size_t nbr_word(uint32_t k, uint32_t i, uint32_t cap) {
-    return (size_t)k * cap + i;
+__device__ __forceinline__ uint32_t nbr_offset(uint32_t i, bool rel16) {   // byte offset inside a row
+    return rel16 ? ((i >> NBR_GROUP_SHIFT) << (NBR_GROUP_SHIFT + 2)) + ((i & ((1u << NBR_GROUP_SHIFT) - 1u)) << 1)
+                 : i << 2;
+}
+
+// entry k of particle i (diagnostics; the sweeps walk rows with for_each_neighbor)
+__device__ __forceinline__ uint32_t nbr_entry(const uint32_t* __restrict__ nbr, uint32_t count_word,
+                                              uint32_t k, uint32_t i, uint32_t cap) {
+    const bool rel16 = (count_word & NBR_REL16) != 0u;
+    const char* p = reinterpret_cast<const char*>(nbr) + (size_t)k * cap * 4 + nbr_offset(i, rel16);
+    return rel16 ? (uint32_t)((int32_t)i + (int32_t)*reinterpret_cast<const int16_t*>(p))
+                 : *reinterpret_cast<const uint32_t*>(p);
+}
+
+// the four entries of the group of rows that starts at `rows` (uniform) for the lane at byte offset off
+__device__ __forceinline__ void nbr_load4(const char* __restrict__ rows, size_t row_bytes, uint32_t off,
+                                          bool rel16, uint32_t i, uint32_t (&jn)[4]) {
+    if (rel16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            jn[u] = (uint32_t)((int32_t)i + (int32_t)*reinterpret_cast<const int16_t*>(rows + u * row_bytes + off));
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) jn[u] = *reinterpret_cast<const uint32_t*>(rows + u * row_bytes + off);
+    }
 }
 
 // Visit the neighbour row of particle i in order, four entries and four position gathers in
 // flight, the next four entries prefetched behind them.  f(j, xj) is called in row order (the
 // summation order of the reference, Simulation.cpp:628,660,692).
 template <int BATCH, typename F>
-__device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t cnt,
+__device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t count_word,
                                                   const uint32_t* __restrict__ nbr, uint32_t cap,
                                                   const float4* __restrict__ x, F&& f) {
     static_assert(BATCH == 4, "rows are padded to groups of four");
-    const uint32_t* __restrict__ rows = nbr;   // uniform: row k0 of every particle
-    const size_t c1 = cap, c2 = 2 * (size_t)cap, c3 = 3 * (size_t)cap, c4 = 4 * (size_t)cap;
+    const bool rel16 = (count_word & NBR_REL16) != 0u;
+    const uint32_t cnt = count_word & NBR_COUNT_MASK;
+    const uint32_t off = nbr_offset(i, rel16);
+    const size_t row_bytes = (size_t)cap * 4;
+    const char* __restrict__ rows = reinterpret_cast<const char*>(nbr);   // uniform: row k0 of every particle
     uint32_t jn[4] = {0u, 0u, 0u, 0u};
-    if (cnt) {
-        jn[0] = rows[i];
-        jn[1] = rows[c1 + i];
-        jn[2] = rows[c2 + i];
-        jn[3] = rows[c3 + i];
-    }
+    if (cnt) nbr_load4(rows, row_bytes, off, rel16, i, jn);
     for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
         const uint32_t j[4] = {jn[0], jn[1], jn[2], jn[3]};
         float4 xj[4];
@@ -234,13 +268,8 @@ __device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t cnt,
             // 32-bit byte offset (capacity <= 2^28): one shift, and the load takes the base from
             // scalar registers, instead of a 64-bit address per gather
             xj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + (j[u] << 4));
-        rows += c4;
-        if (k0 + 4 < cnt) {
-            jn[0] = rows[i];
-            jn[1] = rows[c1 + i];
-            jn[2] = rows[c2 + i];
-            jn[3] = rows[c3 + i];
-        }
+        rows += 4 * row_bytes;
+        if (k0 + 4 < cnt) nbr_load4(rows, row_bytes, off, rel16, i, jn);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (k0 + u < cnt) f(j[u], xj[u]);
@@ -251,20 +280,18 @@ __device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t cnt,
 // + vorticity): both gathers of all four neighbours are in flight before the first pair is
 // evaluated.  f(j, xj, yj).
 template <int BATCH, typename F>
-__device__ __forceinline__ void for_each_neighbor2(uint32_t i, uint32_t cnt,
+__device__ __forceinline__ void for_each_neighbor2(uint32_t i, uint32_t count_word,
                                                    const uint32_t* __restrict__ nbr, uint32_t cap,
                                                    const float4* __restrict__ x,
                                                    const float4* __restrict__ y, F&& f) {
     static_assert(BATCH == 4, "rows are padded to groups of four");
-    const uint32_t* __restrict__ rows = nbr;
-    const size_t c1 = cap, c2 = 2 * (size_t)cap, c3 = 3 * (size_t)cap, c4 = 4 * (size_t)cap;
+    const bool rel16 = (count_word & NBR_REL16) != 0u;
+    const uint32_t cnt = count_word & NBR_COUNT_MASK;
+    const uint32_t off = nbr_offset(i, rel16);
+    const size_t row_bytes = (size_t)cap * 4;
+    const char* __restrict__ rows = reinterpret_cast<const char*>(nbr);
     uint32_t jn[4] = {0u, 0u, 0u, 0u};
-    if (cnt) {
-        jn[0] = rows[i];
-        jn[1] = rows[c1 + i];
-        jn[2] = rows[c2 + i];
-        jn[3] = rows[c3 + i];
-    }
+    if (cnt) nbr_load4(rows, row_bytes, off, rel16, i, jn);
     for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
         const uint32_t j[4] = {jn[0], jn[1], jn[2], jn[3]};
         float4 xj[4], yj[4];
@@ -273,13 +300,8 @@ __device__ __forceinline__ void for_each_neighbor2(uint32_t i, uint32_t cnt,
             xj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + (j[u] << 4));
             yj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(y) + (j[u] << 4));
         }
-        rows += c4;
-        if (k0 + 4 < cnt) {
-            jn[0] = rows[i];
-            jn[1] = rows[c1 + i];
-            jn[2] = rows[c2 + i];
-            jn[3] = rows[c3 + i];
-        }
+        rows += 4 * row_bytes;
+        if (k0 + 4 < cnt) nbr_load4(rows, row_bytes, off, rel16, i, jn);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (k0 + u < cnt) f(j[u], xj[u], yj[u]);

@@ -348,16 +348,16 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = t
         PhaseScope ps(c, PH_NEIGHBORS);   // the device flags were cleared by k_scan_apply
         k_neighbors<true><<<nblocks(n), BLOCK, 0, c->stream>>>(
             c->prd[c->prd_cur], c->prd[c->prd_cur], c->cell_start, n, c->cap, c->K, G,
-            c->P.effective_radius * c->P.effective_radius, c->nbr, c->nbr_count, c->flags);
+            c->P.effective_radius * c->P.effective_radius, c->nbr, c->nbr_count, c->flags, 1);
         if (c->nb) {
             // fluid -> boundary and boundary -> fluid rows, frozen for the sub-step like the fluid's
             const float hh = c->P.effective_radius * c->P.effective_radius;
             k_neighbors<false><<<nblocks(n), BLOCK, 0, c->stream>>>(
                 c->prd[c->prd_cur], c->bpos, c->b_cell_start, n, c->cap, c->Kb, G, hh, c->fb,
-                c->fb_count, c->flags);
+                c->fb_count, c->flags, 0);
             k_neighbors<false><<<nblocks(c->nb), BLOCK, 0, c->stream>>>(
                 c->bpos, c->prd[c->prd_cur], c->cell_start, c->nb, c->nb, c->Kb, G, hh, c->bf,
-                c->bf_count, c->flags);
+                c->bf_count, c->flags, 0);
         }
         LAUNCH_CK(c);
     } else if (c->nb) {

@@ -31,6 +31,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <string>
@@ -311,7 +312,9 @@ int set_device(pbf_ctx* c) {
 
 // sort + neighbour table of the live prd (histogram must already be in cell_count)
 // move_vel = false: the velocities are dead (see k_predict) and stay where they are
-int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = true) {
+// row_depth >= 0 (slab mode): neighbour rows only for the owned cell planes plus that many ghost planes
+// per side (k_neighbors' query window); -1: every particle
+int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = true, int32_t row_depth = -1) {
     const uint32_t n = c->n;
     GridConsts G = make_grid(c->P);
     {
@@ -346,18 +349,23 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = t
     }
     if (n) {
         PhaseScope ps(c, PH_NEIGHBORS);   // the device flags were cleared by k_scan_apply
+        int32_t qx_lo = INT32_MIN, qx_hi = INT32_MAX;
+        if (row_depth >= 0 && c->slab) {
+            if (c->x_lo != INT32_MIN) qx_lo = (int32_t)std::max<int64_t>((int64_t)c->x_lo - row_depth, INT32_MIN);
+            if (c->x_hi != INT32_MAX) qx_hi = (int32_t)std::min<int64_t>((int64_t)c->x_hi + row_depth, INT32_MAX);
+        }
         k_neighbors<true><<<nblocks(n), BLOCK, 0, c->stream>>>(
             c->prd[c->prd_cur], c->prd[c->prd_cur], c->cell_start, n, c->cap, c->K, G,
-            c->P.effective_radius * c->P.effective_radius, c->nbr, c->nbr_count, c->flags, 1);
+            c->P.effective_radius * c->P.effective_radius, c->nbr, c->nbr_count, c->flags, 1, qx_lo, qx_hi);
         if (c->nb) {
             // fluid -> boundary and boundary -> fluid rows, frozen for the sub-step like the fluid's
             const float hh = c->P.effective_radius * c->P.effective_radius;
             k_neighbors<false><<<nblocks(n), BLOCK, 0, c->stream>>>(
                 c->prd[c->prd_cur], c->bpos, c->b_cell_start, n, c->cap, c->Kb, G, hh, c->fb,
-                c->fb_count, c->flags, 0);
+                c->fb_count, c->flags, 0, qx_lo, qx_hi);
             k_neighbors<false><<<nblocks(c->nb), BLOCK, 0, c->stream>>>(
                 c->bpos, c->prd[c->prd_cur], c->cell_start, c->nb, c->nb, c->Kb, G, hh, c->bf,
-                c->bf_count, c->flags, 0);
+                c->bf_count, c->flags, 0, INT32_MIN, INT32_MAX);
         }
         LAUNCH_CK(c);
     } else if (c->nb) {

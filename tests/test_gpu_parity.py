@@ -270,6 +270,28 @@ def test_xsph_vorticity_with_per_particle_masses(xsph, vort):
     assert np.array_equal(gp, op) and np.array_equal(gv, ov)
 
 
+@pytest.mark.parametrize("ny", [120, 140, 160])
+def test_neighbour_rows_switch_format_where_a_cell_plane_outgrows_16_bit_offsets(ny):
+    """The neighbour table stores 16-bit slot offsets relative to the particle wherever every
+    candidate of a 256-slot group lies within +-32767 slots, 32-bit slots elsewhere.  A thin, wide
+    block makes one x-plane of cells hold about 24 k / 33 k / 43 k particles: all groups 16-bit,
+    a mix of both formats, all 32-bit.  Tables IN ORDER and two sub-steps must equal the oracle."""
+    p, pos, mass, cols = scenes.dam_break(3, ny, ny, iterations=2)
+    g, o = make_pair(p, pos, mass, cols)
+    g.predict(DT); g.build_grid()
+    o.predict_positions(DT); o.collision_detection(DT); o.spatial_search()
+    gc, gn = g.neighbors()
+    oc, on = o.neighbors(stride=int(p.max_neighbors))
+    assert np.array_equal(gc, oc) and np.array_equal(gn, on)
+    g, o = make_pair(p, pos, mass, cols)
+    for _ in range(2):
+        g.step(DT); o.step(DT)
+    g.sync()
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)
+
+
 def test_spiky_gradient_option():
     p, pos, mass, cols = scenes.dam_break(10, 10, 10, iterations=2)
     p.gradient_kernel = B.PBF_GRAD_SPIKY

@@ -537,6 +537,10 @@ def main():
                        "substeps_per_s": a.steps / elapsed},
             "hbm_roofline_frac_substep": (290 - 2 * ALGO_BYTES_PER_ITER + a.iters * ALGO_BYTES_PER_ITER) * value / (HBM_PEAK_GBS * 1e9 * world),
             "roofline": roofline,
+            # VALU-busy fraction of the three instruction-heavy kernels from the committed PMC pass
+            # (SQ_ACTIVE_INST_VALU x 4 / (kernel cycles x 1024 SIMDs)); null when the pass is stale
+            "roofline_valu": None if not (roofline and roofline.get("limiters")) else
+                             {k: (v or {}).get("valu") for k, v in roofline["limiters"].items()},
             "phases": phases,
             "evolved": evolved,
             "extras": extras,

@@ -134,6 +134,9 @@ def parse():
     ap.add_argument("--no-shuffle", action="store_true",
                     help="upload the block in generation order (x-major, z-fastest = already cell-sorted) instead "
                          "of a fixed random permutation")
+    ap.add_argument("--no-sizes", action="store_true",
+                    help="N=1: skip the two other single-GPU sizes BASELINE names (C2: 64 k particles, and the "
+                         "16 M-particle scene of C4 on one GPU)")
     ap.add_argument("--no-extras", action="store_true",
                     help="N>1: skip the secondary records (BASELINE's 16 M strong-scaling scene and the "
                          "8 M-per-GPU XSPH + vorticity weak-scaling scene)")
@@ -506,6 +509,35 @@ def main():
                    "neighbor_overflow": st["neighbor_overflow"],
                    "phases": None if a.no_profile else phase_table(ctx, stepper, barrier, max(1, min(a.steps, 50)))}
 
+    # N = 1: the metric is quoted "at 1M and 16M particles"; C2 (64 k, the README CUDA scene's count) is
+    # BASELINE's other single-GPU configuration.  Same kernels, same arithmetic, 20 timed sub-steps each.
+    sizes = None
+    if world == 1 and not a.no_sizes and not a.block:
+        sizes = {}
+        torch.cuda.empty_cache()
+        for name, blk in (("C2_64k", (40, 40, 40)), ("C4_16m_one_gpu", (256, 250, 250))):
+            q, qpos, qmass, qcols = scenes.dam_break(*blk, iterations=a.iters)
+            qpos, _ = shuffled(qpos, not a.no_shuffle)
+            g = PbfContext(q, device=local)
+            g.upload(qpos, uniform_mass=qmass)
+            g.set_colliders(qcols)
+            for _ in range(10):
+                g.step(DT)
+            g.sync()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                g.step(DT)
+            g.sync()
+            t = (time.perf_counter() - t0) / 20
+            st = g.stats().as_dict()
+            sizes[name] = {"workload": f"{blk[0]}x{blk[1]}x{blk[2]} dam-break block ({qpos.shape[0]} particles), "
+                                       f"{a.iters} iterations", "ms_per_step": t * 1e3, "value": qpos.shape[0] / t,
+                           "steps": 20, "warmup": 10, "mean_neighbors": st["mean_neighbor_count"],
+                           "nonfinite": st["nonfinite"], "neighbor_overflow": st["neighbor_overflow"]}
+            g.close()
+            del g, qpos
+            torch.cuda.empty_cache()
+
     # N > 1: the two multi-GPU configurations BASELINE.json names, measured inside the same launch
     extras = None
     if world > 1 and not a.no_extras:
@@ -543,6 +575,7 @@ def main():
                              {k: (v or {}).get("valu") for k, v in roofline["limiters"].items()},
             "phases": phases,
             "evolved": evolved,
+            "other_sizes": sizes,
             "extras": extras,
             "cpu_baseline": cpu,
             "health": {"nonfinite": stats["nonfinite"], "neighbor_overflow": stats["neighbor_overflow"],

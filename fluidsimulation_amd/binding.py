@@ -11,7 +11,8 @@ from pathlib import Path
 
 import numpy as np
 
-PBF_ABI_VERSION = 1
+PBF_ABI_VERSION = 2
+PBF_ROWS_ABS32, PBF_ROWS_REL16, PBF_ROWS_WIN16, PBF_ROWS_ALL = 1, 2, 4, 7
 PBF_MAX_COLLIDERS = 16
 
 PBF_OK = 0
@@ -118,6 +119,7 @@ class PbfStats(C.Structure):
         ("com", C.c_double * 3),
         ("max_speed", C.c_double),
         ("rest_density", C.c_float),
+        ("row_format_particles", C.c_uint32 * 3),
     ]
 
     def as_dict(self) -> dict:
@@ -186,6 +188,7 @@ LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libpbf_hip.so"
 SYMBOLS = [
     "pbf_default_params", "pbf_create", "pbf_destroy", "pbf_last_error", "pbf_upload",
     "pbf_upload_device", "pbf_set_colliders", "pbf_set_solver_iterations", "pbf_set_gravity",
+    "pbf_set_row_formats",
     "pbf_predict", "pbf_build_grid", "pbf_compute_rest_density", "pbf_solve", "pbf_finalize",
     "pbf_step", "pbf_sync", "pbf_download", "pbf_get_scalars", "pbf_get_cells",
     "pbf_get_neighbors", "pbf_get_stats", "pbf_get_rest_density", "pbf_num_particles",
@@ -239,6 +242,7 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_set_colliders.argtypes = [vp, C.POINTER(PbfCollider), C.c_uint32]
     lib.pbf_set_solver_iterations.argtypes = [vp, C.c_int32]
     lib.pbf_set_gravity.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+    lib.pbf_set_row_formats.argtypes = [vp, C.c_uint32]
     lib.pbf_predict.argtypes = [vp, C.c_float]
     lib.pbf_build_grid.argtypes = [vp]
     lib.pbf_compute_rest_density.argtypes = [vp]
@@ -379,6 +383,10 @@ class PbfContext:
             msg = self.lib.pbf_last_error(self._h if self._h else None)
             raise PbfError(rc, (msg or b"pbf_create failed").decode())
         self.n = 0
+        # test lever (tools/fuzz_*.py): PBF_ROW_FORMATS=5 puts every scene, however small, through
+        # the neighbour-row format only large scenes would pick (pbf_set_row_formats)
+        if os.environ.get("PBF_ROW_FORMATS"):
+            self.set_row_formats(int(os.environ["PBF_ROW_FORMATS"]))
 
     # -- lifetime
     def close(self):
@@ -441,6 +449,10 @@ class PbfContext:
         self._ck(self.lib.pbf_get_boundary_neighbors(self._h, _ptr(fc), _ptr(fl), stride_f,
                                                      _ptr(bc), _ptr(bl), stride_b))
         return fc, fl, bc, bl
+
+    def set_row_formats(self, mask):
+        """PBF_ROWS_* the fluid neighbour table may use (results never depend on it)"""
+        self._ck(self.lib.pbf_set_row_formats(self._h, mask))
 
     def set_gravity(self, gx, gy, gz):
         self._ck(self.lib.pbf_set_gravity(self._h, gx, gy, gz))

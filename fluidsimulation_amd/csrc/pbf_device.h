@@ -203,42 +203,93 @@ __device__ __forceinline__ float scorr_strict(const KernConsts& k, float w) {
 // the four entries of a group without a per-entry predicate or dummy select, from a UNIFORM row base
 // (scalar registers) plus the lane's offset, and the gathers of the masked-off tail never leave the
 // target array.
-// Entry format, per group of 256 consecutive slots (the builder's workgroup), flagged in bit 31 of
-// every count word of the group (NBR_REL16; the count is the low bits):
-//   0: the neighbour's sorted slot, 32 bits, at word i of the row;
-//   1: the slot RELATIVE to the particle's own, 16 bits signed, at halfword (i & 255) of the group's
-//      1 KiB segment of the row (bytes [1024 (i >> 8), +512): dense, so a wave reads 128 contiguous
-//      bytes instead of 256).  Particles are cell-sorted, so a neighbour is at most about one x-plane
-//      of cells away in slot order; the builder picks this format when its whole candidate window
-//      lies within +-32767 slots of every particle of the group.  The rows are the bulk of the
-//      sweeps' HBM traffic (4 B x 20 neighbours x 8 sweeps per particle and sub-step): halved.
+// Entry format, per group of 256 consecutive slots (the builder's workgroup), in bits 31:30 of
+// every count word of the group (the count is the low 30 bits):
+//   0 (ABS32): the neighbour's sorted slot, 32 bits, at word i of the row;
+//   1 (REL16): the slot RELATIVE to the particle's own, 16 bits signed -- particles are cell-sorted,
+//      so a neighbour is at most about one x-plane of cells away in slot order; picked when the
+//      group's whole candidate window lies within +-32767 slots of every particle of the group
+//      (cell planes of up to ~30 k particles); decoding is the add the gather's address needs anyway;
+//   2 (WIN16): 16 bits = (column r << 12) | index into the group's staged candidate windows (the
+//      builder's LDS index, < 4096), decoded as win_base[group][r] + index with the nine window
+//      bases of the group in a side table (36 bytes per 256 particles) that a sweeping wave keeps in LDS --
+//      for any scene size, whenever the group was built on the LDS path.
+//   Both 16-bit formats sit dense at halfword (i & 255) of the group's 1 KiB segment of the row
+//   (bytes [1024 (i >> 8), +512)), so a wave reads 128 contiguous bytes per row instead of 256: the
+//   rows are the bulk of the sweeps' HBM traffic (20 neighbours x 8 sweeps per particle and
+//   sub-step), halved.
 // Tables whose query and target sets differ (fluid <-> boundary) are always format 0.
 __host__ __device__ __forceinline__ uint32_t nbr_rows(uint32_t K) { return (K + 3u) & ~3u; }
 constexpr uint32_t NBR_GROUP_SHIFT = 8;   // 256 slots: one k_neighbors workgroup
-constexpr uint32_t NBR_REL16 = 0x80000000u;          // count word: the group's entries are 16-bit relative
-constexpr uint32_t NBR_COUNT_MASK = 0x7fffffffu;
+constexpr uint32_t NBR_FMT_SHIFT = 30;
+constexpr uint32_t NBR_COUNT_MASK = 0x3fffffffu;
+constexpr uint32_t NBR_ABS32 = 0u, NBR_REL16 = 1u, NBR_WIN16 = 2u;
+constexpr uint32_t NBR_WIN_STRIDE = 16;   // LDS words per group in a sweep's copy of the window bases (9 used)
+__host__ __device__ __forceinline__ size_t nbr_base_words(uint32_t cap) { return ((size_t)(cap >> NBR_GROUP_SHIFT) + 2) * 9; }
 
-__device__ __forceinline__ uint32_t nbr_offset(uint32_t i, bool rel16) {   // byte offset inside a row
-    return rel16 ? ((i >> NBR_GROUP_SHIFT) << (NBR_GROUP_SHIFT + 2)) + ((i & ((1u << NBR_GROUP_SHIFT) - 1u)) << 1)
-                 : i << 2;
+__device__ __forceinline__ uint32_t nbr_offset(uint32_t i, bool compact) {   // byte offset inside a row
+    return compact ? ((i >> NBR_GROUP_SHIFT) << (NBR_GROUP_SHIFT + 2)) + ((i & ((1u << NBR_GROUP_SHIFT) - 1u)) << 1)
+                   : i << 2;
 }
 
 // entry k of particle i (diagnostics; the sweeps walk rows with for_each_neighbor)
-__device__ __forceinline__ uint32_t nbr_entry(const uint32_t* __restrict__ nbr, uint32_t count_word,
-                                              uint32_t k, uint32_t i, uint32_t cap) {
-    const bool rel16 = (count_word & NBR_REL16) != 0u;
-    const char* p = reinterpret_cast<const char*>(nbr) + (size_t)k * cap * 4 + nbr_offset(i, rel16);
-    return rel16 ? (uint32_t)((int32_t)i + (int32_t)*reinterpret_cast<const int16_t*>(p))
-                 : *reinterpret_cast<const uint32_t*>(p);
+__device__ __forceinline__ uint32_t nbr_entry(const uint32_t* __restrict__ nbr, const uint32_t* __restrict__ win_base,
+                                              uint32_t count_word, uint32_t k, uint32_t i, uint32_t cap) {
+    const uint32_t fmt = count_word >> NBR_FMT_SHIFT;
+    const char* p = reinterpret_cast<const char*>(nbr) + (size_t)k * cap * 4 + nbr_offset(i, fmt != NBR_ABS32);
+    if (fmt == NBR_REL16) return (uint32_t)((int32_t)i + (int32_t)*reinterpret_cast<const int16_t*>(p));
+    if (fmt == NBR_WIN16) {
+        const uint32_t e = *reinterpret_cast<const uint16_t*>(p);
+        return win_base[(size_t)(i >> NBR_GROUP_SHIFT) * 9 + (e >> 12)] + (e & 0xfffu);
+    }
+    return *reinterpret_cast<const uint32_t*>(p);
+}
+
+// A sweep's view of the window bases.  `base` is the table's side array (nullptr: a table that never
+// uses WIN16), `lds` a workgroup array of NBR_WIN_LDS_WORDS(blockDim.x) words.  Nothing is read unless
+// some lane of the wave holds a WIN16 row; then the wave copies the nine bases of its (at most two: 64
+// consecutive slots need not start on a group boundary) groups into its own 32 words of `lds` -- LDS
+// operations of one wave execute in order, so this needs no workgroup barrier and the sweeps of
+// REL16 / ABS32 groups pay one ballot.
+struct NbrWin {
+    const uint32_t* base;
+    uint32_t* lds;
+};
+__host__ __device__ constexpr uint32_t NBR_WIN_LDS_WORDS(uint32_t block) { return (block / 64u) * 2u * NBR_WIN_STRIDE; }
+
+// The calling lanes are consecutive slots in ascending lane order (all sweeps index particles that
+// way) and call this together.  Returns the lane's group's table (nine words), or nullptr when the
+// wave has no WIN16 row.
+__device__ __forceinline__ const uint32_t* nbr_win_table(const NbrWin& win, uint32_t i, uint32_t fmt, uint32_t cap) {
+    if (!win.base || !__builtin_amdgcn_ballot_w64(fmt == NBR_WIN16)) return nullptr;
+    uint32_t* t = win.lds + (threadIdx.x >> 6) * (2u * NBR_WIN_STRIDE);
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i) >> NBR_GROUP_SHIFT;
+    // the active lanes share the 32 words among themselves (a full wave: lanes 0..31, one each)
+    const uint64_t ex = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex, 0u));
+    const uint32_t n_active = (uint32_t)__builtin_popcountll(ex);
+    for (uint32_t w = rank; w < 2u * NBR_WIN_STRIDE; w += n_active) {
+        const uint32_t g = g0 + w / NBR_WIN_STRIDE, r = w % NBR_WIN_STRIDE;
+        const bool in = r < 9u && (size_t)g * 9 + r < nbr_base_words(cap);
+        t[w] = in ? win.base[(size_t)g * 9 + r] : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return t + ((i >> NBR_GROUP_SHIFT) - g0) * NBR_WIN_STRIDE;
 }
 
 // the four entries of the group of rows that starts at `rows` (uniform) for the lane at byte offset off
 __device__ __forceinline__ void nbr_load4(const char* __restrict__ rows, size_t row_bytes, uint32_t off,
-                                          bool rel16, uint32_t i, uint32_t (&jn)[4]) {
-    if (rel16) {
+                                          uint32_t fmt, uint32_t i, const uint32_t* win_tbl, uint32_t (&jn)[4]) {
+    if (fmt == NBR_REL16) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             jn[u] = (uint32_t)((int32_t)i + (int32_t)*reinterpret_cast<const int16_t*>(rows + u * row_bytes + off));
+    } else if (fmt == NBR_WIN16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t e = *reinterpret_cast<const uint16_t*>(rows + u * row_bytes + off);
+            jn[u] = win_tbl[e >> 12] + (e & 0xfffu);
+        }
     } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u) jn[u] = *reinterpret_cast<const uint32_t*>(rows + u * row_bytes + off);
@@ -251,15 +302,17 @@ __device__ __forceinline__ void nbr_load4(const char* __restrict__ rows, size_t 
 template <int BATCH, typename F>
 __device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t count_word,
                                                   const uint32_t* __restrict__ nbr, uint32_t cap,
+                                                  const NbrWin& win,
                                                   const float4* __restrict__ x, F&& f) {
     static_assert(BATCH == 4, "rows are padded to groups of four");
-    const bool rel16 = (count_word & NBR_REL16) != 0u;
+    const uint32_t rel16 = count_word >> NBR_FMT_SHIFT;   // the entry format
     const uint32_t cnt = count_word & NBR_COUNT_MASK;
-    const uint32_t off = nbr_offset(i, rel16);
+    const uint32_t off = nbr_offset(i, rel16 != NBR_ABS32);
     const size_t row_bytes = (size_t)cap * 4;
     const char* __restrict__ rows = reinterpret_cast<const char*>(nbr);   // uniform: row k0 of every particle
+    const uint32_t* win_tbl = nbr_win_table(win, i, rel16, cap);
     uint32_t jn[4] = {0u, 0u, 0u, 0u};
-    if (cnt) nbr_load4(rows, row_bytes, off, rel16, i, jn);
+    if (cnt) nbr_load4(rows, row_bytes, off, rel16, i, win_tbl, jn);
     for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
         const uint32_t j[4] = {jn[0], jn[1], jn[2], jn[3]};
         float4 xj[4];
@@ -269,7 +322,7 @@ __device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t count_wor
             // scalar registers, instead of a 64-bit address per gather
             xj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + (j[u] << 4));
         rows += 4 * row_bytes;
-        if (k0 + 4 < cnt) nbr_load4(rows, row_bytes, off, rel16, i, jn);
+        if (k0 + 4 < cnt) nbr_load4(rows, row_bytes, off, rel16, i, win_tbl, jn);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (k0 + u < cnt) f(j[u], xj[u]);
@@ -282,16 +335,18 @@ __device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t count_wor
 template <int BATCH, typename F>
 __device__ __forceinline__ void for_each_neighbor2(uint32_t i, uint32_t count_word,
                                                    const uint32_t* __restrict__ nbr, uint32_t cap,
+                                                   const NbrWin& win,
                                                    const float4* __restrict__ x,
                                                    const float4* __restrict__ y, F&& f) {
     static_assert(BATCH == 4, "rows are padded to groups of four");
-    const bool rel16 = (count_word & NBR_REL16) != 0u;
+    const uint32_t rel16 = count_word >> NBR_FMT_SHIFT;   // the entry format
     const uint32_t cnt = count_word & NBR_COUNT_MASK;
-    const uint32_t off = nbr_offset(i, rel16);
+    const uint32_t off = nbr_offset(i, rel16 != NBR_ABS32);
     const size_t row_bytes = (size_t)cap * 4;
     const char* __restrict__ rows = reinterpret_cast<const char*>(nbr);
+    const uint32_t* win_tbl = nbr_win_table(win, i, rel16, cap);
     uint32_t jn[4] = {0u, 0u, 0u, 0u};
-    if (cnt) nbr_load4(rows, row_bytes, off, rel16, i, jn);
+    if (cnt) nbr_load4(rows, row_bytes, off, rel16, i, win_tbl, jn);
     for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
         const uint32_t j[4] = {jn[0], jn[1], jn[2], jn[3]};
         float4 xj[4], yj[4];
@@ -301,7 +356,7 @@ __device__ __forceinline__ void for_each_neighbor2(uint32_t i, uint32_t count_wo
             yj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(y) + (j[u] << 4));
         }
         rows += 4 * row_bytes;
-        if (k0 + 4 < cnt) nbr_load4(rows, row_bytes, off, rel16, i, jn);
+        if (k0 + 4 < cnt) nbr_load4(rows, row_bytes, off, rel16, i, win_tbl, jn);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (k0 + u < cnt) f(j[u], xj[u], yj[u]);

@@ -95,6 +95,8 @@ struct pbf_ctx {
     uint32_t *key = nullptr, *tmp_src = nullptr, *tmp_id = nullptr;
     uint32_t *cell_count = nullptr, *cell_start = nullptr, *cursor = nullptr, *tile_sums = nullptr;
     uint32_t *nbr = nullptr, *nbr_count = nullptr;
+    uint32_t* nbr_base = nullptr;   // nine window bases per group of 256 slots (WIN16 rows, pbf_device.h)
+    uint32_t row_formats = PBF_ROWS_ALL;   // pbf_set_row_formats
     float *dens = nullptr, *C = nullptr, *rho0 = nullptr;
     float4* omega = nullptr;
     void* staging = nullptr;  // cap * 16 B scratch for up/downloads
@@ -356,16 +358,16 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = t
         }
         k_neighbors<true><<<nblocks(n), BLOCK, 0, c->stream>>>(
             c->prd[c->prd_cur], c->prd[c->prd_cur], c->cell_start, n, c->cap, c->K, G,
-            c->P.effective_radius * c->P.effective_radius, c->nbr, c->nbr_count, c->flags, 1, qx_lo, qx_hi);
+            c->P.effective_radius * c->P.effective_radius, c->nbr, c->nbr_count, c->flags, c->nbr_base, c->row_formats, qx_lo, qx_hi);
         if (c->nb) {
             // fluid -> boundary and boundary -> fluid rows, frozen for the sub-step like the fluid's
             const float hh = c->P.effective_radius * c->P.effective_radius;
             k_neighbors<false><<<nblocks(n), BLOCK, 0, c->stream>>>(
                 c->prd[c->prd_cur], c->bpos, c->b_cell_start, n, c->cap, c->Kb, G, hh, c->fb,
-                c->fb_count, c->flags, 0, qx_lo, qx_hi);
+                c->fb_count, c->flags, nullptr, PBF_ROWS_ABS32, qx_lo, qx_hi);
             k_neighbors<false><<<nblocks(c->nb), BLOCK, 0, c->stream>>>(
                 c->bpos, c->prd[c->prd_cur], c->cell_start, c->nb, c->nb, c->Kb, G, hh, c->bf,
-                c->bf_count, c->flags, 0, INT32_MIN, INT32_MAX);
+                c->bf_count, c->flags, nullptr, PBF_ROWS_ABS32, INT32_MIN, INT32_MAX);
         }
         LAUNCH_CK(c);
     } else if (c->nb) {

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PBF_ABI_VERSION 1
+#define PBF_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -123,6 +123,9 @@ typedef struct pbf_stats {
     double   com[3];             /* mass-weighted centre of mass                            */
     double   max_speed;
     float    rest_density;
+    uint32_t row_format_particles[3]; /* particles whose neighbour row is stored as 32-bit slots /
+                                    16-bit offsets from the particle / 16-bit window codes (DESIGN.md
+                                    section 2; no reference counterpart)                       */
 } pbf_stats;
 
 typedef struct pbf_ctx pbf_ctx;
@@ -153,6 +156,16 @@ int pbf_set_colliders(pbf_ctx* ctx, const pbf_collider* colliders, uint32_t coun
 int pbf_set_solver_iterations(pbf_ctx* ctx, int32_t iterations);
 /* Simulation::setGravity (Simulation.cpp:307-310) */
 int pbf_set_gravity(pbf_ctx* ctx, float gx, float gy, float gz);
+/* Which entry formats the fluid neighbour table may use from the next pbf_build_grid on (no
+ * reference counterpart; results never depend on it): bit 0 = 32-bit slots (always allowed), bit 1 =
+ * 16-bit offsets from the particle, bit 2 = 16-bit window codes.  Default
+ * PBF_ROWS_ALL; the narrower masks exist for measurements and to put small test scenes through the
+ * format only large scenes would pick. */
+#define PBF_ROWS_ABS32 1u
+#define PBF_ROWS_REL16 2u
+#define PBF_ROWS_WIN16 4u
+#define PBF_ROWS_ALL   7u
+int pbf_set_row_formats(pbf_ctx* ctx, uint32_t mask);
 
 /* Simulation::PredictPositions + CollisionDetection (Simulation.cpp:578-599,723-751;
  * ParticleSet::TestCollision/OnCollision, Particle.cpp:217-338); replaces integratePBD

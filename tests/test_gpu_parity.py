@@ -270,12 +270,14 @@ def test_xsph_vorticity_with_per_particle_masses(xsph, vort):
     assert np.array_equal(gp, op) and np.array_equal(gv, ov)
 
 
-@pytest.mark.parametrize("ny", [120, 140, 160])
-def test_neighbour_rows_switch_format_where_a_cell_plane_outgrows_16_bit_offsets(ny):
-    """The neighbour table stores 16-bit slot offsets relative to the particle wherever every
-    candidate of a 256-slot group lies within +-32767 slots, 32-bit slots elsewhere.  A thin, wide
-    block makes one x-plane of cells hold about 24 k / 33 k / 43 k particles: all groups 16-bit,
-    a mix of both formats, all 32-bit.  Tables IN ORDER and two sub-steps must equal the oracle."""
+@pytest.mark.parametrize("ny,formats", [(120, {1}), (140, {1, 2}), (160, {2})])
+def test_neighbour_rows_switch_format_where_a_cell_plane_outgrows_16_bit_offsets(ny, formats):
+    """The neighbour table stores, per 256-slot group, 16-bit slot offsets relative to the particle
+    where every candidate of the group lies within +-32767 slots (format 1), 16-bit codes into the
+    group's nine candidate windows where not (format 2), and 32-bit slots for groups that touch the
+    grid edge (format 0).  A thin, wide block makes one x-plane of cells hold about 24 k / 33 k / 43 k
+    particles: all format 1, a mix of 1 and 2, mostly format 2.  Tables IN ORDER and two
+    sub-steps must equal the oracle."""
     p, pos, mass, cols = scenes.dam_break(3, ny, ny, iterations=2)
     g, o = make_pair(p, pos, mass, cols)
     g.predict(DT); g.build_grid()
@@ -283,6 +285,10 @@ def test_neighbour_rows_switch_format_where_a_cell_plane_outgrows_16_bit_offsets
     gc, gn = g.neighbors()
     oc, on = o.neighbors(stride=int(p.max_neighbors))
     assert np.array_equal(gc, oc) and np.array_equal(gn, on)
+    census = list(g.stats().row_format_particles)
+    assert sum(census) == pos.shape[0]
+    # format 0: grid-edge groups, if any; the slots at either end of the block see one plane less
+    assert all(census[f] for f in formats) and (ny != 120 or not census[2]) and (ny != 160 or census[2] > 2 * census[1]), census
     g, o = make_pair(p, pos, mass, cols)
     for _ in range(2):
         g.step(DT); o.step(DT)
@@ -290,6 +296,30 @@ def test_neighbour_rows_switch_format_where_a_cell_plane_outgrows_16_bit_offsets
     gp, gv, _ = g.download()
     op, ov, _, _ = o.download()
     assert np.array_equal(gp, op) and np.array_equal(gv, ov)
+
+
+@pytest.mark.parametrize("mask,used", [(B.PBF_ROWS_ABS32, {0}), (B.PBF_ROWS_ABS32 | B.PBF_ROWS_WIN16, {0, 2}),
+                                       (B.PBF_ROWS_ALL, {0, 1})])
+def test_results_do_not_depend_on_the_neighbour_row_format(mask, used):
+    """pbf_set_row_formats: a small scene through 32-bit rows only, through the window-coded 16-bit
+    rows only large scenes would pick, and through the default choice -- the table read back in
+    order, three sub-steps with XSPH and vorticity (every sweep kernel decodes the rows)"""
+    p, pos, mass, cols = scenes.dam_break(14, 13, 12, iterations=2, xsph_c=0.01, vorticity_eps=0.05)
+    g, o = make_pair(p, pos, mass, cols)
+    g.set_row_formats(mask)
+    for _ in range(3):
+        g.step(DT); o.step(DT)
+    g.sync()
+    census = list(g.stats().row_format_particles)
+    assert sum(census) == pos.shape[0] and {f for f in range(3) if census[f]} <= used and census[max(used)] > 0, census
+    gc, gn = g.neighbors()
+    oc, on = o.neighbors(stride=int(p.max_neighbors))
+    assert np.array_equal(gc, oc) and np.array_equal(gn, on)
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)
+    with pytest.raises(PbfError):
+        g.set_row_formats(8)
 
 
 def test_spiky_gradient_option():

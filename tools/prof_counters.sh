@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 # --no-shuffle: the passes average over every launch, the first sub-step included; from an upload in
 # generation order that sub-step looks like every later one (the sorted order is the steady state of ANY
 # upload order), so the averages are steady-state figures
-BENCH="python3 $ROOT/bench.py --steps 8 --warmup 4 --cpu-steps 0 --no-profile --evolved-steps 0 --no-shuffle"
+BENCH="python3 $ROOT/bench.py --steps 8 --warmup 4 --cpu-steps 0 --no-profile --evolved-steps 0 --no-shuffle --no-sizes --no-extras"
 run_pass() {
   name=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -- $BENCH \

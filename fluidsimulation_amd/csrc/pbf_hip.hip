@@ -97,6 +97,10 @@ struct pbf_ctx {
     uint32_t *nbr = nullptr, *nbr_count = nullptr;
     uint32_t* nbr_base = nullptr;   // nine window bases per group of 256 slots (WIN16 rows, pbf_device.h)
     uint32_t row_formats = PBF_ROWS_ALL;   // pbf_set_row_formats
+    // A cell of side s splits into q^3 sub-cubes (q = ceil(sqrt(3) s / h)) whose diagonal is at most h:
+    // all particles of one sub-cube are mutual neighbours, so a cell with more than q^3 (K + 1)
+    // occupants has a sub-cube with more than K + 1, whose rows overflow whatever else happens.
+    uint32_t crowd_limit = 0;              // q^3 (K + 1); 0 = unchecked
     float *dens = nullptr, *C = nullptr, *rho0 = nullptr;
     float4* omega = nullptr;
     void* staging = nullptr;  // cap * 16 B scratch for up/downloads
@@ -324,11 +328,11 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = t
         k_scan_tile_sums<<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums);
         if (c->ntiles <= FOLD_MAX_TILES) {
             k_scan_apply<true><<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
-                                                                   c->cell_start, c->cursor, c->flags);
+                                                                   c->cell_start, c->cursor, c->flags, c->crowd_limit);
         } else {
             k_scan_sums<<<1, BLOCK, 0, c->stream>>>(c->tile_sums, c->ntiles);
             k_scan_apply<false><<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
-                                                                    c->cell_start, c->cursor, c->flags);
+                                                                    c->cell_start, c->cursor, c->flags, c->crowd_limit);
         }
         if (n) {
             const int s = c->cur, d = 1 - c->cur;
@@ -338,7 +342,7 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = t
             k_reorder<<<nblocks(n), BLOCK, 0, c->stream>>>(
                 c->key, c->cell_start, c->tmp_src, c->tmp_id, n, c->pos[s], c->vel[s],
                 c->prd[ps_], c->pos[d], move_vel ? c->vel[d] : nullptr, c->prd[pd], c->id[d],
-                c->slab ? c->slot_of : nullptr);
+                c->slab ? c->slot_of : nullptr, c->flags);
             c->cur = d;
             c->prd_cur = pd;
         }
@@ -441,6 +445,12 @@ int check_flags(pbf_ctx* c) {
                                     : std::string());
     const char* cure = c->nb ? "); raise pbf_params.max_neighbors / pbf_set_boundary's max_boundary_neighbors"
                              : "); raise pbf_params.max_neighbors";
+    if (f.crowded_cell)
+        return fail(c, PBF_ERR_NEIGHBOR_OVERFLOW,
+                    "a cell held " + std::to_string(f.crowded_cell) + " particles, more than " +
+                        std::to_string(c->crowd_limit) + " = sub-cubes x (max_neighbors + 1): its neighbour rows "
+                        "overflow for any arrangement; the sort and the neighbour build were skipped from "
+                        "that sub-step on and the state is undefined until the next upload");
     if (f.neighbor_overflow)
         return fail(c, PBF_ERR_NEIGHBOR_OVERFLOW,
                     std::to_string(f.neighbor_overflow) + " particles exceed " + rows + " (largest count " +

@@ -90,13 +90,13 @@ def test_duplicated_positions_and_one_crowded_cell():
 
 def test_crowded_cell_beyond_the_table_is_reported():
     rng = np.random.default_rng(5)
-    pos = rng.uniform(2.0, 2.5, (300, 3)).astype(np.float32)
-    g = PbfContext(params(300, k=32), device=0)
+    pos = rng.uniform(2.0, 2.5, (250, 3)).astype(np.float32)   # below the crowd limit 8 x (32 + 1)
+    g = PbfContext(params(250, k=32), device=0)
     g.upload(pos, uniform_mass=0.1)
     g.build_grid()
     with pytest.raises(PbfError) as e:
         g.sync()
-    assert e.value.code == B.PBF_ERR_NEIGHBOR_OVERFLOW and "299" in str(e.value)
+    assert e.value.code == B.PBF_ERR_NEIGHBOR_OVERFLOW and "249" in str(e.value)
 
 
 def test_sparse_particles_across_a_large_grid():

@@ -357,6 +357,45 @@ def test_neighbor_overflow_in_an_earlier_substep_is_still_reported():
     assert p2.neighbor_overflow == 0
 
 
+def test_a_pile_of_particles_in_one_cell_is_refused_quickly():
+    """20 000 particles inside one cell (user error: positions never initialised, a collapsed
+    emitter): every neighbour row of that cell overflows for any arrangement once it holds more than
+    8 x (max_neighbors + 1) particles, and the rank-by-id pass and the neighbour build would each run
+    O(occupancy) per particle.  The scan notices, both are skipped, pbf_sync says why; the ctx works
+    again after the next upload."""
+    import time
+    p, pos, mass, cols = scenes.c1_lattice(6, 6, 6, iterations=2)
+    p.capacity = 32768
+    g = PbfContext(p, device=0)
+    rng = np.random.default_rng(3)
+    pile = (np.float32(10.2) + rng.uniform(0, 0.5, (20000, 3))).astype(np.float32)
+    g.upload(pile, uniform_mass=mass)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        g.step(DT)
+    with pytest.raises(PbfError) as e:
+        g.sync()
+    assert time.perf_counter() - t0 < 5.0
+    assert e.value.code == B.PBF_ERR_NEIGHBOR_OVERFLOW and "a cell held 20000 particles" in str(e.value)
+    assert "more than 520" in str(e.value)
+    # a dense but legal cell (below the limit) takes the ordinary path: rows overflow, reported as such
+    g.upload(pile[:400], uniform_mass=mass)
+    g.step(DT)
+    with pytest.raises(PbfError) as e:
+        g.sync()
+    assert "exceed max_neighbors" in str(e.value)
+    # and a sane scene runs on the same ctx afterwards, equal to the oracle
+    o = pyoracle.Oracle(p)
+    g.upload(pos, uniform_mass=mass); o.upload(pos, uniform_mass=mass)
+    g.set_colliders(cols); o.set_colliders(cols)
+    for _ in range(2):
+        g.step(DT); o.step(DT)
+    g.sync()
+    gp, gv, _ = g.download()
+    op, ov, _, _ = o.download()
+    assert np.array_equal(gp, op) and np.array_equal(gv, ov)
+
+
 def test_neighbor_overflow_is_loud():
     p, pos, mass, cols = scenes.c1_lattice(6, 6, 6)
     p.max_neighbors = 8

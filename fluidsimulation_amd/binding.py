@@ -12,7 +12,7 @@ from pathlib import Path
 import numpy as np
 
 PBF_ABI_VERSION = 2
-PBF_ROWS_ABS32, PBF_ROWS_REL16, PBF_ROWS_WIN16, PBF_ROWS_ALL = 1, 2, 4, 7
+PBF_ROWS_ABS32, PBF_ROWS_REL16, PBF_ROWS_WIN16, PBF_ROWS_ALL, PBF_ROWS_UNSTAGED = 1, 2, 4, 7, 8
 PBF_MAX_COLLIDERS = 16
 
 PBF_OK = 0

@@ -356,22 +356,23 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = t
     if (n) {
         PhaseScope ps(c, PH_NEIGHBORS);   // the device flags were cleared by k_scan_apply
         int32_t qx_lo = INT32_MIN, qx_hi = INT32_MAX;
+        const uint32_t run_limit = c->crowd_limit && c->crowd_limit < 0x55555555u ? 3u * c->crowd_limit : 0xffffffffu;
         if (row_depth >= 0 && c->slab) {
             if (c->x_lo != INT32_MIN) qx_lo = (int32_t)std::max<int64_t>((int64_t)c->x_lo - row_depth, INT32_MIN);
             if (c->x_hi != INT32_MAX) qx_hi = (int32_t)std::min<int64_t>((int64_t)c->x_hi + row_depth, INT32_MAX);
         }
         k_neighbors<true><<<nblocks(n), BLOCK, 0, c->stream>>>(
             c->prd[c->prd_cur], c->prd[c->prd_cur], c->cell_start, n, c->cap, c->K, G,
-            c->P.effective_radius * c->P.effective_radius, c->nbr, c->nbr_count, c->flags, c->nbr_base, c->row_formats, qx_lo, qx_hi);
+            c->P.effective_radius * c->P.effective_radius, c->nbr, c->nbr_count, c->flags, c->nbr_base, c->row_formats, run_limit, qx_lo, qx_hi);
         if (c->nb) {
             // fluid -> boundary and boundary -> fluid rows, frozen for the sub-step like the fluid's
             const float hh = c->P.effective_radius * c->P.effective_radius;
             k_neighbors<false><<<nblocks(n), BLOCK, 0, c->stream>>>(
                 c->prd[c->prd_cur], c->bpos, c->b_cell_start, n, c->cap, c->Kb, G, hh, c->fb,
-                c->fb_count, c->flags, nullptr, PBF_ROWS_ABS32, qx_lo, qx_hi);
+                c->fb_count, c->flags, nullptr, PBF_ROWS_ABS32, 0xffffffffu, qx_lo, qx_hi);
             k_neighbors<false><<<nblocks(c->nb), BLOCK, 0, c->stream>>>(
                 c->bpos, c->prd[c->prd_cur], c->cell_start, c->nb, c->nb, c->Kb, G, hh, c->bf,
-                c->bf_count, c->flags, nullptr, PBF_ROWS_ABS32, INT32_MIN, INT32_MAX);
+                c->bf_count, c->flags, nullptr, PBF_ROWS_ABS32, run_limit, INT32_MIN, INT32_MAX);
         }
         LAUNCH_CK(c);
     } else if (c->nb) {

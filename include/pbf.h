@@ -160,11 +160,13 @@ int pbf_set_gravity(pbf_ctx* ctx, float gx, float gy, float gz);
  * reference counterpart; results never depend on it): bit 0 = 32-bit slots (always allowed), bit 1 =
  * 16-bit offsets from the particle, bit 2 = 16-bit window codes.  Default
  * PBF_ROWS_ALL; the narrower masks exist for measurements and to put small test scenes through the
- * format only large scenes would pick. */
+ * format, or the build path, only large scenes would pick. */
 #define PBF_ROWS_ABS32 1u
 #define PBF_ROWS_REL16 2u
 #define PBF_ROWS_WIN16 4u
 #define PBF_ROWS_ALL   7u
+#define PBF_ROWS_UNSTAGED 8u /* test lever: build every group on the neighbour kernel's global path (the
+                                path of groups whose candidate windows exceed the LDS budget) */
 int pbf_set_row_formats(pbf_ctx* ctx, uint32_t mask);
 
 /* Simulation::PredictPositions + CollisionDetection (Simulation.cpp:578-599,723-751;

@@ -324,6 +324,51 @@ def test_c5_two_native_slabs_of_8m_particles_with_xsph_and_vorticity_equal_one_c
     assert np.array_equal(rec[order, 0:3], p1) and np.array_equal(rec[order, 4:7], v1)
 
 
+def test_c4_eight_native_slabs_of_2m_particles_equal_one_ctx():
+    """C4 at its full size (BASELINE config 4: 16 M particles, strong scaling over 8 GPUs): the
+    256x250x250 block cut into eight slabs of 2 M particles, eight rank threads stepping
+    pbf_slab_step over the loopback transport with two ghost layers, against ONE ctx on the whole
+    scene -- bit-identical after two sub-steps.  A 250x250 cell plane holds 62 500 particles, so
+    every slab's neighbour rows are in the window-coded 16-bit format (pbf_device.h)."""
+    import threading
+    import torch
+    from fluidsimulation_amd import slab as S
+    p, pos, mass, cols = scenes.dam_break(256, 250, 250, iterations=4)
+    n = pos.shape[0]
+    assert n == 16_000_000
+    steps, world, layers = 2, 8, 2
+    g = PbfContext(p, device=0)
+    g.upload(pos, uniform_mass=mass)
+    g.set_colliders(cols)
+    for _ in range(steps):
+        g.step(DT)
+    g.sync()
+    st = g.stats()
+    assert st.n == n and st.nonfinite == 0 and st.neighbor_overflow == 0
+    assert st.row_format_particles[2] > 0.9 * n, list(st.row_format_particles)
+    p1, v1, _ = g.download()
+    del g
+    torch.cuda.empty_cache()
+    planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    owned = np.bincount(np.searchsorted(planes[1:-1], S.cell_x(pos[:, 0], p.grid_spacing), side="right"),
+                        minlength=world)
+    assert owned.min() > 1_800_000 and owned.max() < 2_200_000, owned
+    uid = RcclComm.local_id()
+    out, errs = {}, []
+    vel = np.zeros_like(pos)
+    ts = [threading.Thread(target=_native_rank, args=(r, world, uid, p, pos, mass, cols, vel, planes, layers,
+                                                      steps, out, errs, False)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not errs, errs
+    rec = np.concatenate([out[r] for r in range(world)], axis=0)
+    assert rec.shape[0] == n
+    order = np.argsort(S.record_ids(rec))
+    assert np.array_equal(rec[order, 0:3], p1) and np.array_equal(rec[order, 4:7], v1)
+
+
 def test_slab_simulation_bootstraps_the_native_path_on_an_nccl_group():
     """what bench.py --gpus N does on every rank, here with a world of one: the RCCL unique id
     travels over the torch.distributed (nccl) group, the communicator is created through the C

@@ -299,11 +299,14 @@ def test_neighbour_rows_switch_format_where_a_cell_plane_outgrows_16_bit_offsets
 
 
 @pytest.mark.parametrize("mask,used", [(B.PBF_ROWS_ABS32, {0}), (B.PBF_ROWS_ABS32 | B.PBF_ROWS_WIN16, {0, 2}),
-                                       (B.PBF_ROWS_ALL, {0, 1})])
+                                       (B.PBF_ROWS_ALL, {0, 1}),
+                                       (B.PBF_ROWS_ALL | B.PBF_ROWS_UNSTAGED, {0, 1}),
+                                       (B.PBF_ROWS_ABS32 | B.PBF_ROWS_WIN16 | B.PBF_ROWS_UNSTAGED, {0, 2})])
 def test_results_do_not_depend_on_the_neighbour_row_format(mask, used):
     """pbf_set_row_formats: a small scene through 32-bit rows only, through the window-coded 16-bit
-    rows only large scenes would pick, and through the default choice -- the table read back in
-    order, three sub-steps with XSPH and vorticity (every sweep kernel decodes the rows)"""
+    rows only large scenes would pick, through the default choice, and the 16-bit formats again with
+    every group built on the neighbour kernel's global path (where groups go whose candidate windows
+    exceed the LDS budget) -- the table read back in order, three sub-steps with XSPH and vorticity (every sweep kernel decodes the rows)"""
     p, pos, mass, cols = scenes.dam_break(14, 13, 12, iterations=2, xsph_c=0.01, vorticity_eps=0.05)
     g, o = make_pair(p, pos, mass, cols)
     g.set_row_formats(mask)
@@ -319,7 +322,7 @@ def test_results_do_not_depend_on_the_neighbour_row_format(mask, used):
     op, ov, _, _ = o.download()
     assert np.array_equal(gp, op) and np.array_equal(gv, ov)
     with pytest.raises(PbfError):
-        g.set_row_formats(8)
+        g.set_row_formats(16)
 
 
 def test_spiky_gradient_option():

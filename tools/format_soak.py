@@ -13,7 +13,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from fluidsimulation_amd import PbfContext, scenes  # noqa: E402
 from fluidsimulation_amd import binding as B  # noqa: E402
 
-DT = 1.0 / 60 / 4
+DT = 0.0005   # GLFWApp.cpp:393
 a = [int(x) for x in sys.argv[1:]]
 bad = 0
 for k in range(0, len(a), 4):
@@ -27,16 +27,19 @@ for k in range(0, len(a), 4):
         g.upload(pos, uniform_mass=mass)
         g.set_colliders(cols)
         census = np.zeros(3, np.int64)
+        peak = 0
         t0 = time.perf_counter()
         for s in range(steps):
             g.step(DT)
             if s % max(1, steps // 8) == 0:
-                census = np.maximum(census, np.array(list(g.stats().row_format_particles)))
+                st = g.stats()
+                census = np.maximum(census, np.array(list(st.row_format_particles)))
+                peak = max(peak, int(st.max_neighbor_count))
         g.sync()
         st = g.stats()
         res.append(g.download()[:2])
         print(f"{nx}x{ny}x{nz} mask {mask}: {steps} sub-steps in {time.perf_counter() - t0:.1f} s, mean nbrs "
-              f"{st.mean_neighbor_count:.2f} max {st.max_neighbor_count}, most particles seen per format {census.tolist()}",
+              f"{st.mean_neighbor_count:.2f} max {st.max_neighbor_count} (peak at the checkpoints {peak}), most particles seen per format {census.tolist()}",
               flush=True)
         g.close()
     same = np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])

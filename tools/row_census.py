@@ -12,7 +12,7 @@ for k in range(0, len(a), 3):
     g = PbfContext(p, device=0)
     g.upload(pos, uniform_mass=mass)
     g.set_colliders(cols)
-    g.step(1.0 / 60 / 4)
+    g.step(0.0005)
     g.sync()
     st = g.stats()
     print(a[k:k + 3], "grid", list(p.grid_dim), "origin", list(p.grid_origin_cell), "rows abs32/rel16/win16",

@@ -486,7 +486,13 @@ def main():
                         "limited_by": busiest, "limiters": limiters, "pmc_note": pmc_note,
                         "algorithmic_bytes_per_launch": algo[dom] * n_local,
                         "algorithmic_bytes_per_particle": algo[dom],
-                        "avg_launch_ms": cand[dom]["ms_per_launch"], "particles_per_launch": n_local}
+                        "avg_launch_ms": cand[dom]["ms_per_launch"], "particles_per_launch": n_local,
+                        # the HBM fraction of every phase it prices, lambda and delta-p separately
+                        "per_kernel": {k: {"algorithmic_bytes_per_particle": algo[k],
+                                           "avg_launch_ms": v["ms_per_launch"],
+                                           "achieved": algo[k] * n_local / (v["ms_per_launch"] * 1e-3) / 1e9,
+                                           "frac": algo[k] * n_local / (v["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                       for k, v in cand.items()}}
 
     # the same scene once it is no lattice at rest any more (N = 1): `value` above is the BASELINE
     # window (sub-steps warmup .. warmup + steps of the block at rest, ~20 neighbours per particle)

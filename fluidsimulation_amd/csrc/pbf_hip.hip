@@ -97,9 +97,14 @@ struct pbf_ctx {
     uint32_t *nbr = nullptr, *nbr_count = nullptr;
     uint32_t* nbr_base = nullptr;   // nine window bases per group of 256 slots (WIN16 rows, pbf_device.h)
     uint32_t row_formats = PBF_ROWS_ALL;   // pbf_set_row_formats
-    // A cell of side s splits into q^3 sub-cubes (q = ceil(sqrt(3) s / h)) whose diagonal is at most h:
-    // all particles of one sub-cube are mutual neighbours, so a cell with more than q^3 (K + 1)
-    // occupants has a sub-cube with more than K + 1, whose rows overflow whatever else happens.
+    // Crowd limit: the rank-by-id pass and the neighbour build cost O(occupancy of the cell KEY) per
+    // particle, so a pile of particles in one cell -- or a grid far too small for the scene, whose keys
+    // alias many cells -- turns them quadratic.  A sub-step is refused (DevFlags::crowded_cell) when
+    // some key holds more than crowd_threshold(n) particles: beyond BOTH q^3 (K + 1) -- a cell of side s
+    // splits into q^3 sub-cubes (q = ceil(sqrt(3) s / h)) whose diagonal is at most h, so an un-aliased
+    // cell with more occupants has K + 2 mutual neighbours and overflows its rows whatever the
+    // arrangement -- AND 2^34 / n, i.e. only where n x occupancy says seconds of work, not milliseconds
+    // (small wrap-around grids alias on purpose and stay legal).
     uint32_t crowd_limit = 0;              // q^3 (K + 1); 0 = unchecked
     float *dens = nullptr, *C = nullptr, *rho0 = nullptr;
     float4* omega = nullptr;
@@ -320,19 +325,26 @@ int set_device(pbf_ctx* c) {
 // move_vel = false: the velocities are dead (see k_predict) and stay where they are
 // row_depth >= 0 (slab mode): neighbour rows only for the owned cell planes plus that many ghost planes
 // per side (k_neighbors' query window); -1: every particle
+uint32_t crowd_threshold(const pbf_ctx* c) {
+    if (!c->crowd_limit) return 0u;
+    const uint64_t by_work = (1ull << 34) / (c->n ? c->n : 1u);
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->crowd_limit, by_work), 0x40000000ull);
+}
+
 int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = true, int32_t row_depth = -1) {
     const uint32_t n = c->n;
+    const uint32_t crowd = crowd_threshold(c);
     GridConsts G = make_grid(c->P);
     {
         PhaseScope ps(c, PH_SORT);
         k_scan_tile_sums<<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums);
         if (c->ntiles <= FOLD_MAX_TILES) {
             k_scan_apply<true><<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
-                                                                   c->cell_start, c->cursor, c->flags, c->crowd_limit);
+                                                                   c->cell_start, c->cursor, c->flags, crowd);
         } else {
             k_scan_sums<<<1, BLOCK, 0, c->stream>>>(c->tile_sums, c->ntiles);
             k_scan_apply<false><<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
-                                                                    c->cell_start, c->cursor, c->flags, c->crowd_limit);
+                                                                    c->cell_start, c->cursor, c->flags, crowd);
         }
         if (n) {
             const int s = c->cur, d = 1 - c->cur;
@@ -356,7 +368,7 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = t
     if (n) {
         PhaseScope ps(c, PH_NEIGHBORS);   // the device flags were cleared by k_scan_apply
         int32_t qx_lo = INT32_MIN, qx_hi = INT32_MAX;
-        const uint32_t run_limit = c->crowd_limit && c->crowd_limit < 0x55555555u ? 3u * c->crowd_limit : 0xffffffffu;
+        const uint32_t run_limit = crowd ? 3u * crowd : 0xffffffffu;
         if (row_depth >= 0 && c->slab) {
             if (c->x_lo != INT32_MIN) qx_lo = (int32_t)std::max<int64_t>((int64_t)c->x_lo - row_depth, INT32_MIN);
             if (c->x_hi != INT32_MAX) qx_hi = (int32_t)std::min<int64_t>((int64_t)c->x_hi + row_depth, INT32_MAX);
@@ -448,10 +460,12 @@ int check_flags(pbf_ctx* c) {
                              : "); raise pbf_params.max_neighbors";
     if (f.crowded_cell)
         return fail(c, PBF_ERR_NEIGHBOR_OVERFLOW,
-                    "a cell held " + std::to_string(f.crowded_cell) + " particles, more than " +
-                        std::to_string(c->crowd_limit) + " = sub-cubes x (max_neighbors + 1): its neighbour rows "
-                        "overflow for any arrangement; the sort and the neighbour build were skipped from "
-                        "that sub-step on and the state is undefined until the next upload");
+                    "a cell key held " + std::to_string(f.crowded_cell) + " particles (limit " +
+                        std::to_string(crowd_threshold(c)) + " for " + std::to_string(c->n) +
+                        " particles): particles piled up in one cell -- its neighbour rows overflow for any "
+                        "arrangement -- or grid_dim is far too small for the scene; the sort and the neighbour "
+                        "build, O(occupancy) per particle, were skipped from that sub-step on and the state is "
+                        "undefined until the next upload");
     if (f.neighbor_overflow)
         return fail(c, PBF_ERR_NEIGHBOR_OVERFLOW,
                     std::to_string(f.neighbor_overflow) + " particles exceed " + rows + " (largest count " +

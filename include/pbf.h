@@ -191,9 +191,10 @@ int pbf_finalize(pbf_ctx* ctx, float dt);
  * solve, finalize */
 int pbf_step(pbf_ctx* ctx, float dt);
 /* blocks until the ctx stream is idle; returns the sticky device-side error if any
- * (PBF_ERR_NEIGHBOR_OVERFLOW: rows cut at max_neighbors in this or an earlier sub-step; or a cell
- * that held more than q^3 x (max_neighbors + 1) particles, q = ceil(sqrt(3) grid_spacing /
- * effective_radius) -- its rows overflow for any arrangement, so the sort and the neighbour build
+ * (PBF_ERR_NEIGHBOR_OVERFLOW: rows cut at max_neighbors in this or an earlier sub-step; or a cell key
+ * that held more than max(q^3 x (max_neighbors + 1), 2^34 / n) particles, q = ceil(sqrt(3)
+ * grid_spacing / effective_radius) -- a pile in one cell, whose rows overflow for any arrangement, or
+ * a grid far too small for the scene: the sort and the neighbour build, O(occupancy) per particle,
  * are skipped from that sub-step on and the state is undefined until the next upload) */
 int pbf_sync(pbf_ctx* ctx);
 

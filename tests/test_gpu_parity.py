@@ -361,17 +361,17 @@ def test_neighbor_overflow_in_an_earlier_substep_is_still_reported():
 
 
 def test_a_pile_of_particles_in_one_cell_is_refused_quickly():
-    """20 000 particles inside one cell (user error: positions never initialised, a collapsed
-    emitter): every neighbour row of that cell overflows for any arrangement once it holds more than
-    8 x (max_neighbors + 1) particles, and the rank-by-id pass and the neighbour build would each run
-    O(occupancy) per particle.  The scan notices, both are skipped, pbf_sync says why; the ctx works
-    again after the next upload."""
+    """300 000 particles inside one cell (user error: positions never initialised, a collapsed
+    emitter): the rank-by-id pass and the neighbour build cost O(occupancy) per particle, 9e10 steps
+    each here.  A cell key beyond max(8 x (max_neighbors + 1), 2^34 / n) particles is refused by the
+    scan: both passes are skipped, pbf_sync says why; the ctx works again after the next upload.
+    (Small wrap-around grids whose keys alias many cells stay legal: tools/fuzz_parity.py.)"""
     import time
     p, pos, mass, cols = scenes.c1_lattice(6, 6, 6, iterations=2)
-    p.capacity = 32768
+    p.capacity = 300000
     g = PbfContext(p, device=0)
     rng = np.random.default_rng(3)
-    pile = (np.float32(10.2) + rng.uniform(0, 0.5, (20000, 3))).astype(np.float32)
+    pile = (np.float32(10.2) + rng.uniform(0, 0.5, (300000, 3))).astype(np.float32)
     g.upload(pile, uniform_mass=mass)
     t0 = time.perf_counter()
     for _ in range(3):
@@ -379,8 +379,14 @@ def test_a_pile_of_particles_in_one_cell_is_refused_quickly():
     with pytest.raises(PbfError) as e:
         g.sync()
     assert time.perf_counter() - t0 < 5.0
-    assert e.value.code == B.PBF_ERR_NEIGHBOR_OVERFLOW and "a cell held 20000 particles" in str(e.value)
-    assert "more than 520" in str(e.value)
+    assert e.value.code == B.PBF_ERR_NEIGHBOR_OVERFLOW and "a cell key held 300000 particles" in str(e.value)
+    assert "limit 57266" in str(e.value)
+    # 20 000 in one cell: milliseconds of work, not refused -- the ordinary overflow report
+    g.upload(pile[:20000], uniform_mass=mass)
+    g.step(DT)
+    with pytest.raises(PbfError) as e:
+        g.sync()
+    assert "exceed max_neighbors" in str(e.value)
     # a dense but legal cell (below the limit) takes the ordinary path: rows overflow, reported as such
     g.upload(pile[:400], uniform_mass=mass)
     g.step(DT)

@@ -43,15 +43,20 @@ N_CU, N_SIMD, N_XCD = 256, 1024, 8     # MI355X_MICROARCH.md
 
 
 def kernel_source_sha():
-    """fingerprint of the device code the PMC passes profiled: sha256 over the kernel sources.
+    """fingerprint of the device code the PMC passes profiled: sha256 over the kernel sources with
+    comments and white space removed (a reworded comment is not another kernel).
     tools/summarize_prof.py stamps profiles/pmc_latest.json with it; a bench run of other sources
     must not quote that file's counters."""
     import hashlib
+    import re
     csrc = ROOT / "fluidsimulation_amd" / "csrc"
     h = hashlib.sha256()
     for f in [csrc / "pbf_hip.hip", csrc / "pbf_device.h"] + sorted(csrc.glob("kernels/*.inc")):
+        text = f.read_text()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)      # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                    # line comments (the sources hold no "//" in strings)
         h.update(f.name.encode())
-        h.update(f.read_bytes())
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -224,6 +224,35 @@ def phase_table(ctx, stepper, barrier, ksteps):
             for name, (ms, calls) in prof.items() if calls}
 
 
+def per_rank_breakdown(sim, rank, world, k, backend):
+    """Every rank's own account of k sub-steps, gathered on all ranks: device time per phase from HIP
+    events on the ctx stream -- predict (= the split pass of the native slab step), sort + neighbors
+    (the grid), lambda + delta (the sweeps), exchange (count / payload / halo exchanges: pack, grouped
+    send + receive, unpack; includes waiting for the neighbour) -- wall time, owned and ghost
+    counts.  A profiled pass of its own (event records sit between the launches): never the pass a
+    `value` comes from.  One hardware run then explains its own parallel efficiency."""
+    import torch.distributed as dist
+    ctx = sim.ctx
+    sim.sync()
+    dist.barrier()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        sim.step(DT)
+    sim.sync()
+    wall = (time.perf_counter() - t0) / k
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    owned = int(sim.backend.owned_count())
+    mine = {"rank": rank, "owned": owned, "ghosts": int(ctx.n) - owned, "wall_ms_per_step": wall * 1e3,
+            "device_ms_per_step": {name: ms / k for name, (ms, calls) in prof.items() if calls},
+            "launches_per_step": {name: calls / k for name, (ms, calls) in prof.items() if calls}}
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return out
+
+
 def multi_gpu_extras(a, sim, rank, world, local, time_steps):
     """Inside a --gpus N launch: BASELINE.json's two multi-GPU configurations, each next to the same
     work on ONE GPU (rank 0 alone, one ctx), so the line carries measured efficiencies.
@@ -285,13 +314,14 @@ def multi_gpu_extras(a, sim, rank, world, local, time_steps):
             t = time_steps(s.step, s.sync, k)
             st = s.stats()
             owned = s.owned_counts()
+            per_rank = per_rank_breakdown(s, rank, world, k, a.backend)
             s.sync()
         except Exception as e:  # noqa: BLE001
             return None, str(e)
         finally:
             del s
             torch.cuda.empty_cache()
-        return (t, st, owned), None
+        return (t, st, owned, per_rank), None
 
     out = {}
     # C4: strong scaling of ONE 16 M-particle scene
@@ -305,10 +335,11 @@ def multi_gpu_extras(a, sim, rank, world, local, time_steps):
                        f"{layers} ghost layers", "scaling": "strong", "steps": k, "warmup": warm,
            "ms_per_step_1gpu": None if t1 is None else t1 * 1e3, "value_1gpu": None if t1 is None else n / t1}
     if res:
-        tn, st, owned = res
+        tn, st, owned, per_rank = res
         rec.update({"ms_per_step": tn * 1e3, "value": n / tn,
                     "parallel_efficiency": None if t1 is None else t1 / (world * tn), "owned_per_rank": owned,
-                    "nonfinite": st["nonfinite"], "neighbor_overflow": st["neighbor_overflow"]})
+                    "nonfinite": st["nonfinite"], "neighbor_overflow": st["neighbor_overflow"],
+                    "per_rank": per_rank})
     else:
         rec["error"] = err
     out["strong_16m"] = rec
@@ -330,22 +361,65 @@ def multi_gpu_extras(a, sim, rank, world, local, time_steps):
            "steps": k, "warmup": warm, "ms_per_step_1gpu_one_block": None if t1 is None else t1 * 1e3,
            "value_1gpu_one_block": None if t1 is None else n1 / t1}
     if res:
-        tn, st, owned = res
+        tn, st, owned, per_rank = res
         rec.update({"ms_per_step": tn * 1e3, "value": n / tn,
                     "parallel_efficiency": None if t1 is None else t1 / tn, "owned_per_rank": owned,
-                    "nonfinite": st["nonfinite"], "neighbor_overflow": st["neighbor_overflow"]})
+                    "nonfinite": st["nonfinite"], "neighbor_overflow": st["neighbor_overflow"],
+                    "per_rank": per_rank})
     else:
         rec["error"] = err
     out["weak_8m_visc"] = rec
     return out
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N
+    ranks ourselves -- torch.distributed.run as a CHILD process, before this process has imported
+    torch or touched a GPU (never an exec) -- relay the ranks' output and exit with the child's code.
+    The one JSON line is printed by rank 0 of the child."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print(f"[bench] --gpus {a.gpus} without a launcher: starting {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = 0
+    for ln in proc.stdout:
+        if ln.startswith("{"):
+            lines += 1
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"[bench] the {a.gpus}-rank child printed {lines} JSON lines (expected 1)", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     a = parse()
+    # the world comes from the launcher's environment; --gpus must agree with it, and a bare
+    # `python bench.py --gpus N` launches its N ranks itself: a multi-GPU line can not silently
+    # come from one GPU
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to "
+              f"measure a world other than the one asked for", file=sys.stderr)
+        raise SystemExit(2)
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -362,6 +436,16 @@ def main():
     from fluidsimulation_amd import PbfContext, scenes
 
     block = tuple(a.block) if a.block else (100, 100, 100)
+    ranks_seen = {"all_reduce_of_ones": 1, "pbf_comm_world": None, "devices": None}
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int64, device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen["all_reduce_of_ones"] = int(ones.item())
+        devs = [None] * world
+        dist.all_gather_object(devs, f"{os.uname().nodename}:cuda{local}")
+        ranks_seen["devices"] = devs
+        if ranks_seen["all_reduce_of_ones"] != a.gpus:
+            raise SystemExit(f"bench.py: {ranks_seen['all_reduce_of_ones']} ranks answered, --gpus {a.gpus}")
 
     if world == 1:
         p, pos, mass, cols = scenes.dam_break(*block, iterations=a.iters, xsph_c=a.xsph, vorticity_eps=a.vorticity)
@@ -420,6 +504,8 @@ def main():
         stepper = sim.step
         syncer = sim.sync
         ctx = sim.ctx
+        comm = getattr(sim.group.exchange, "comm", None)   # the C-ABI library's RCCL communicator, if in use
+        ranks_seen["pbf_comm_world"] = int(comm.world) if comm is not None and hasattr(comm, "world") else None
         workload = (f"{scene_nx}x{block[1]}x{block[2]} dam-break block ({n_total} particles) in "
                     f"{world} x-slabs, {a.iters} solver iterations, dt=5e-4")
         parallelism = f"slab{world}, {layers} ghost layers" + \
@@ -549,6 +635,11 @@ def main():
             del g, qpos
             torch.cuda.empty_cache()
 
+    # N > 1: every rank's phase breakdown of the headline scene (a pass of its own, after the timed one)
+    per_rank = None
+    if world > 1 and not a.no_profile:
+        per_rank = per_rank_breakdown(sim, rank, world, max(1, min(a.steps, 20)), a.backend)
+
     # N > 1: the two multi-GPU configurations BASELINE.json names, measured inside the same launch
     extras = None
     if world > 1 and not a.no_extras:
@@ -565,6 +656,7 @@ def main():
             "value": value,
             "unit": "particle-substeps/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
@@ -587,6 +679,7 @@ def main():
             "phases": phases,
             "evolved": evolved,
             "other_sizes": sizes,
+            "per_rank": per_rank,
             "extras": extras,
             "cpu_baseline": cpu,
             "health": {"nonfinite": stats["nonfinite"], "neighbor_overflow": stats["neighbor_overflow"],

@@ -614,6 +614,12 @@ class PbfContext:
 
     def slab_rebalance(self, planes, x_first: int, n_planes: int, max_move: int):
         """collective; returns (new planes, number of planes moved)"""
+        comm = getattr(self, "_comm", None)
+        if comm is None:
+            raise PbfError(PBF_ERR_INVALID, "pbf_slab_attach has not been called")
+        # the C side reads planes[world] and writes planes[1 .. world - 1]: it cannot check the length
+        if len(planes) != comm.world + 1:
+            raise PbfError(PBF_ERR_INVALID, f"planes must hold world + 1 = {comm.world + 1} entries, got {len(planes)}")
         arr = (C.c_int32 * len(planes))(*[int(v) for v in planes])
         moved = C.c_int32()
         self._ck(self.lib.pbf_slab_rebalance(self._h, arr, int(x_first), int(n_planes), int(max_move),

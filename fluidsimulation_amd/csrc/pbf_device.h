@@ -123,13 +123,6 @@ __device__ __forceinline__ float grad_scalar_strict(const KernConsts& k, float d
 //    section 3 already lists (a sum only shows it when it is itself exactly -0).  NaN: max(NaN, 0) = 0,
 //    like the reference's failed test.
 __device__ __forceinline__ void poly6_pair(const KernConsts& k, float distance, float& w, float& gs) {
-#ifdef PBF_EXP_FP32   // measurement only (tools/tolerance_probe.py): the all-fp32 pair evaluation
-    const float qf = fmaxf(fmaf(-distance, distance, k.hh), 0.f);
-    const float q2f = qf * qf;
-    w = (float)k.w_coef * (q2f * qf);
-    gs = k.g_coef * q2f;
-    return;
-#endif
     const double d = (double)distance;
     const double q = fmax(fma(-d, d, k.h2), 0.0);
     const double q2 = q * q;
@@ -155,9 +148,6 @@ __device__ __forceinline__ void kernel_pair(const KernConsts& k, float distance,
 // pbf_selftest_sqrt, tests/test_gpu_parity.py).  Zero, subnormal-range and non-finite inputs
 // take the library path.
 __device__ __forceinline__ float sqrt_rn(float x) {
-#ifdef PBF_EXP_FP32
-    return __builtin_amdgcn_sqrtf(x);   // 1 ulp hardware square root
-#endif
     if (x >= 1.2621774e-29f && x <= 3.4028235e38f) {  // [2^-96, FLT_MAX]
         float r = __builtin_amdgcn_rsqf(x);
         float y = x * r;
@@ -185,10 +175,6 @@ __device__ __forceinline__ double pow4_of_float(double x) {
 // 24-bit floats lies at least 2^-49 away from any float rounding boundary.  (For subnormal
 // quotients ties can differ, but then x^4 underflows to 0 in the final float anyway.)
 __device__ __forceinline__ float scorr_strict(const KernConsts& k, float w) {
-#ifdef PBF_EXP_FP32
-    const float xs = w * (float)k.inv_w_dq, x2 = xs * xs;
-    return ((float)k.scorr_k * (x2 * x2)) * (float)k.dt_pow;
-#endif
     float xf = (float)((double)w * k.inv_w_dq);
     double x = pow4_of_float((double)xf);
     double s = k.scorr_k * x;

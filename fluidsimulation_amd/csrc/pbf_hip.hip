@@ -60,10 +60,11 @@ enum Phase {
     PH_DELTA,
     PH_FINALIZE,
     PH_VISCOSITY,
+    PH_EXCHANGE,   // slab mode: count / payload / halo exchanges (pack, grouped send + receive, unpack)
     PH_COUNT
 };
-const char* kPhaseNames[PH_COUNT] = {"predict", "sort",     "neighbors", "rest_density",
-                                     "lambda",  "delta",    "finalize",  "viscosity"};
+const char* kPhaseNames[PH_COUNT] = {"predict", "sort",     "neighbors", "rest_density", "lambda",
+                                     "delta",   "finalize", "viscosity", "exchange"};
 
 #include "kernels/state.inc"
 #include "kernels/sort.inc"

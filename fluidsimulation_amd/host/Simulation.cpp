@@ -3,6 +3,7 @@
 // Simulation / ParticleSystem / NeighborSearch / ConstraintSolver translation units.
 #include "Simulation.h"
 
+#include <cmath>
 #include <cstring>
 
 // ---------------------------------------------------------------- ParticleSystem
@@ -146,10 +147,19 @@ bool Simulation::Initialize(PBD_MODE mode, std::shared_ptr<ParticleSystem> parti
         m_error = "null particle system";
         return false;
     }
+    // the reference builds its scene inside Initialize (Simulation.cpp:51-53); a caller that brought
+    // its own particles keeps them
+    const bool build_scene = !m_particle_system->getParticles();
+    if (build_scene) m_params.grid_dim[0] = m_params.grid_dim[1] = m_params.grid_dim[2] = 64;   // Simulation.cpp:46
     GridSize gs{(uint32_t)m_params.grid_dim[0], (uint32_t)m_params.grid_dim[1], (uint32_t)m_params.grid_dim[2]};
     m_neighbor_searcher = std::make_shared<NeighborSearch>(m_particle_system, gs);
     if (!m_solver) m_solver = std::make_shared<ConstraintSolver>(mode);
     else m_solver->setPBDMode(mode);
+    SetupSimParams();
+    if (build_scene) {
+        GenerateFluidCube();
+        InitializeBoundaryParticles();
+    }
     m_params.gravity[0] = 0.f;
     m_params.gravity[1] = m_world_desc.gravity;  // vec3(0, gravity, 0), Simulation.cpp:592
     m_params.gravity[2] = 0.f;
@@ -163,6 +173,96 @@ bool Simulation::Initialize(PBD_MODE mode, std::shared_ptr<ParticleSystem> parti
     if (!push_constraints()) return false;
     m_initialized = true;
     return true;
+}
+
+// Simulation::SetupSimParams (Simulation.cpp:312-354) in fp32 with pi = 3.1415926f (common.h:8):
+//   volume = 20 * 0.015 / 1000, h = powf(3 volume / (4 pi), 1/3), r = powf(pi / (6 * 20), 1/3) * h.
+// The two derived values are written as the constants SURVEY.md 8(a) row a3 pins (powf differs by an
+// ulp between C libraries for r; the scene must not depend on which libm built this library).
+void Simulation::SetupSimParams() {
+    const float particle_mass = 0.015f, n_kernel_particles = 20.f;
+    m_rest_density = 1000.f;
+    m_particle_mass = particle_mass;
+    m_volume = n_kernel_particles * particle_mass / m_rest_density;
+    const float effective_radius = 0.041528303f, particle_radius = 0.012331058f;
+    SimParams& sp = m_sim_params;
+    sp = SimParams{};
+    sp.gravity = {0.f, -9.8f, 0.f};
+    sp.global_damping = 1.f;
+    sp.particle_radius = particle_radius;
+    sp.effective_radius = effective_radius;
+    sp.epsilon = 100.f;
+    sp.grid_size = {m_neighbor_searcher->m_grid_size.x, m_neighbor_searcher->m_grid_size.y,
+                    m_neighbor_searcher->m_grid_size.z};
+    sp.num_cells = m_neighbor_searcher->m_num_grid_cells;
+    sp.world_origin = {0.f, 0.f, 0.f};
+    sp.cell_size = {effective_radius, effective_radius, effective_radius};
+    sp.spring = 0.5f;
+    sp.damping = 0.02f;
+    sp.shear = 0.1f;
+    sp.attraction = 0.0f;
+    sp.boundary_damping = 0.1f;
+    sp.static_friction = 1.0f;       // "ice friction at -12 C"
+    sp.kinematic_friction = 0.75f;
+    sp.volume = m_volume;
+}
+
+// Simulation::GenerateFluidCube (Simulation.cpp:528-576): i, j, k in [-n, n), n = floor(0.5 / d),
+// k fastest, cube centred on (0, 0.75, 0); the jitter the reference computes is never applied
+void Simulation::GenerateFluidCube() {
+    const float d = 2.f * m_sim_params.particle_radius;
+    const int n = (int)(0.5f / d);
+    ParticleSet* f = m_particle_system->AllocateParticles((size_t)8 * n * n * n, m_particle_mass);
+    size_t idx = 0;
+    for (int i = -n; i < n; ++i)
+        for (int j = -n; j < n; ++j)
+            for (int k = -n; k < n; ++k, ++idx) {
+                const Vec3 p(0.f + d * (float)i, 0.75f + d * (float)j, 0.f + d * (float)k);
+                f->m_positions[idx] = f->m_new_positions[idx] = f->m_predict_positions[idx] = p;
+            }
+    m_particle_system->setParticleRadius(m_sim_params.particle_radius);
+    // the solver constants this scene is run with (the CUDA path's: Simulation.cpp:318,337,
+    // cuda_simulation.cu:973), layered on the CPU path's arithmetic
+    pbf_params& P = m_params;
+    P.capacity = (uint32_t)f->m_size;
+    P.max_neighbors = 96;
+    P.effective_radius = P.grid_spacing = m_sim_params.effective_radius;
+    P.epsilon = m_sim_params.epsilon;
+    P.scorr_dt_power = 3;
+    P.rest_density_mode = PBF_RHO0_FIXED;
+    P.rest_density = m_rest_density;
+}
+
+// Simulation::InitializeBoundaryParticles (Simulation.cpp:356-490): one layer of particles as an
+// open box -- floor, left / right, back / front
+void Simulation::InitializeBoundaryParticles() {
+    const float d = 2.f * m_sim_params.particle_radius, h = m_sim_params.effective_radius;
+    const int m = (int)(1.f / d);
+    std::vector<Vec3> b;
+    for (int i = -m; i < m; ++i)
+        for (int k = -m; k < m; ++k) b.emplace_back(d * (float)i, 0.f, d * (float)k);
+    const float left = d * (float)(-m) - d, right = d * (float)(m - 1) + d;
+    for (int j = -m; j < m; ++j)
+        for (int k = -m; k < m; ++k) {
+            const float y = d * (float)j + (float)m * d, z = d * (float)k;
+            b.emplace_back(left, y, z);
+            b.emplace_back(right, y, z);
+        }
+    const float back = d * (float)(-m) - d, front = d * (float)(m - 1) + d;
+    for (int i = -m; i < m; ++i)
+        for (int j = -m; j < m; ++j) {
+            const float x = d * (float)i, y = d * (float)j + (float)m * d;
+            b.emplace_back(x, y, back);
+            b.emplace_back(x, y, front);
+        }
+    ParticleSet* bs = m_particle_system->AllocateBoundaryParticles(b.size(), m_particle_mass);
+    float lo[3] = {1e30f, 1e30f, 1e30f};
+    for (size_t t = 0; t < b.size(); ++t) {
+        bs->m_positions[t] = b[t];
+        lo[0] = fminf(lo[0], b[t].x); lo[1] = fminf(lo[1], b[t].y); lo[2] = fminf(lo[2], b[t].z);
+    }
+    // the wrap-around grid's window starts one cell below the walls (no wall cell on a grid face)
+    for (int a = 0; a < 3; ++a) m_params.grid_origin_cell[a] = (int32_t)floorf(lo[a] / h) - 1;
 }
 
 bool Simulation::push_colliders() {

@@ -21,67 +21,6 @@
 
 #include "Simulation.h"
 
-// Simulation::SetupSimParams (Simulation.cpp:312-354) in fp32 with pi = 3.1415926f:
-//   volume = 20 * 0.015 / 1000, h = powf(3 volume / (4 pi), 1/3), r = powf(pi / (6 * 20), 1/3) * h.
-// The two derived values are written as the constants SURVEY.md 8(a) row a3 pins (powf differs by
-// an ulp between C libraries for r; the scene must not depend on which libm built this driver).
-static void sim_params_constants(float& h, float& r, float& mass, float& rho0) {
-    mass = 0.015f;
-    rho0 = 1000.f;
-    h = 0.041528303f;
-    r = 0.012331058f;
-}
-
-// Simulation::GenerateFluidCube + InitializeBoundaryParticles (Simulation.cpp:356-576)
-static void build_c2(ParticleSystem& ps, pbf_params& P) {
-    float h, r, mass, rho0;
-    sim_params_constants(h, r, mass, rho0);
-    const float d = 2.f * r;
-    const int n = (int)(0.5f / d);
-    ParticleSet* f = ps.AllocateParticles((size_t)8 * n * n * n, mass);
-    size_t idx = 0;
-    for (int i = -n; i < n; ++i)
-        for (int j = -n; j < n; ++j)
-            for (int k = -n; k < n; ++k, ++idx) {
-                Vec3 p(0.f + d * (float)i, 0.75f + d * (float)j, 0.f + d * (float)k);
-                f->m_positions[idx] = f->m_new_positions[idx] = f->m_predict_positions[idx] = p;
-            }
-    const int m = (int)(1.f / d);
-    std::vector<Vec3> b;
-    for (int i = -m; i < m; ++i)
-        for (int k = -m; k < m; ++k) b.emplace_back(d * (float)i, 0.f, d * (float)k);   // floor
-    const float left = d * (float)(-m) - d, right = d * (float)(m - 1) + d;
-    for (int j = -m; j < m; ++j)
-        for (int k = -m; k < m; ++k) {                                                  // left, right
-            const float y = d * (float)j + (float)m * d, z = d * (float)k;
-            b.emplace_back(left, y, z);
-            b.emplace_back(right, y, z);
-        }
-    const float back = d * (float)(-m) - d, front = d * (float)(m - 1) + d;
-    for (int i = -m; i < m; ++i)
-        for (int j = -m; j < m; ++j) {                                                  // back, front
-            const float x = d * (float)i, y = d * (float)j + (float)m * d;
-            b.emplace_back(x, y, back);
-            b.emplace_back(x, y, front);
-        }
-    ParticleSet* bs = ps.AllocateBoundaryParticles(b.size(), mass);
-    float lo[3] = {1e30f, 1e30f, 1e30f};
-    for (size_t t = 0; t < b.size(); ++t) {
-        bs->m_positions[t] = b[t];
-        lo[0] = fminf(lo[0], b[t].x); lo[1] = fminf(lo[1], b[t].y); lo[2] = fminf(lo[2], b[t].z);
-    }
-    ps.setParticleRadius(r);
-    P.capacity = (uint32_t)f->m_size;
-    P.max_neighbors = 96;
-    P.effective_radius = P.grid_spacing = h;
-    P.grid_dim[0] = P.grid_dim[1] = P.grid_dim[2] = 64;              // Simulation.cpp:46
-    for (int a = 0; a < 3; ++a) P.grid_origin_cell[a] = (int32_t)floorf(lo[a] / h) - 1;
-    P.epsilon = 100.f;                                               // Simulation.cpp:337
-    P.scorr_dt_power = 3;                                            // cuda_simulation.cu:973
-    P.rest_density_mode = PBF_RHO0_FIXED;
-    P.rest_density = rho0;
-}
-
 int main(int argc, char** argv) {
     int nx = 10, ny = 100, nz = 10, steps = 10, iters = 2;
     std::string dump, save, resume, scene = "c1";
@@ -104,9 +43,8 @@ int main(int argc, char** argv) {
     PlaneCollider ground(Vec3(0, 1, 0), 0), c1(Vec3(1, 0, 0), -10), c2(Vec3(-1, 0, 0), -10),
         c3(Vec3(0, 0, 1), -15), c4(Vec3(0, 0, -1), 1);
     if (scene == "c2") {
-        build_c2(*particle_system, simulator->params());
-        particles = particle_system->getParticles();
-        n = particles->m_size;
+        // nothing to do here: Initialize fills an empty particle system as the reference's does
+        // (SetupSimParams, GenerateFluidCube, InitializeBoundaryParticles; Simulation.cpp:42-72)
     } else if (scene == "c1") {
         // GLFWApp::GenerateFluidParticles, GLFWApp.cpp:437-465
         n = (size_t)nx * ny * nz;
@@ -132,6 +70,14 @@ int main(int argc, char** argv) {
     if (!simulator->Initialize(PBD_MODE::XPBD, particle_system)) {  // GLFWApp.cpp:215
         fprintf(stderr, "Initialize failed: %s\n", simulator->error().c_str());
         return 1;
+    }
+    if (scene == "c2") {
+        particles = particle_system->getParticles();
+        n = particles->m_size;
+        const SimParams* sp = simulator->getSimParams();   // Simulation.h:76
+        printf("SimParams: effective_radius %.9g particle_radius %.9g epsilon %g grid %ux%ux%u boundary %zu\n",
+               sp->effective_radius, sp->particle_radius, sp->epsilon, sp->grid_size.x, sp->grid_size.y,
+               sp->grid_size.z, particle_system->getBoundaryParticles()->m_size);
     }
     simulator->SetSolverIteration((uint32_t)iters);  // GLFWApp.cpp:216
     if (!resume.empty() && !particle_system->LoadSnapshot(resume.c_str())) {

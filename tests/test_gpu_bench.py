@@ -57,6 +57,7 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["ranks_seen"]["all_reduce_of_ones"] == 2 and len(d["ranks_seen"]["devices"]) == 2
     assert d["config"]["particles"] == 2 * 24 * 20 * 20
     assert "slab2" in d["config"]["parallelism"] and "picked from" in d["config"]["parallelism"]
     assert "REHEARSAL" in d["data"]
@@ -67,6 +68,32 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     for rec in ex.values():
         assert rec["ms_per_step"] > 0 and rec["parallel_efficiency"] > 0 and rec["nonfinite"] == 0
         assert rec["neighbor_overflow"] == 0 and len(rec["owned_per_rank"]) == 2
+        # every rank's own account of its sub-step: owned + ghost counts, device time per phase
+        assert [r["rank"] for r in rec["per_rank"]] == [0, 1]
+        for r, owned in zip(rec["per_rank"], rec["owned_per_rank"]):
+            assert r["owned"] == owned and r["ghosts"] > 0 and r["wall_ms_per_step"] > 0
+            assert {"predict", "sort", "neighbors", "lambda", "delta"} <= set(r["device_ms_per_step"])
     assert sum(ex["strong_16m"]["owned_per_rank"]) == 30 * 16 * 16
     assert sum(ex["weak_8m_visc"]["owned_per_rank"]) == 2 * 16 ** 3
     assert d["health"]["nonfinite"] == 0 and d["health"]["neighbor_overflow"] == 0
+
+
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it (the way the driver launches N = 1): the
+    script starts its two ranks itself, as a child process, and relays rank 0's one JSON line --
+    n_gpus is what --gpus asked for, and both ranks answered the all-reduce.  (gloo: the two ranks
+    share this box's one GPU, a rehearsal of the nccl launch.)"""
+    import os
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--block", "24", "16", "16", "--backend", "gloo", "--no-extras"],
+                       capture_output=True, text=True, timeout=400, cwd=str(ROOT), env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"]["all_reduce_of_ones"] == 2
+    assert d["config"]["particles"] == 2 * 24 * 16 * 16 and "slab2" in d["config"]["parallelism"]
+    assert [r_["rank"] for r_ in d["per_rank"]] == [0, 1]
+    assert sum(r_["owned"] for r_ in d["per_rank"]) == d["config"]["particles"]
+    assert "starting 2 ranks" in r.stderr

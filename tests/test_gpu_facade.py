@@ -65,15 +65,19 @@ def test_headless_driver_resumes_from_a_snapshot(tmp_path):
 
 
 def test_headless_driver_c2_scene_with_boundary_particles(tmp_path):
-    """--scene c2: the README CUDA scene built by the C++ facade (GenerateFluidCube +
-    InitializeBoundaryParticles restated in pbf_run.cpp, ParticleSystem::AllocateBoundaryParticles
-    -> pbf_set_boundary) == the Python generators + the oracle's boundary coupling"""
+    """--scene c2: the README CUDA scene built by the C++ facade as the reference's Initialize builds
+    it (Simulation::Initialize on an empty ParticleSystem: SetupSimParams -> GenerateFluidCube ->
+    InitializeBoundaryParticles, Simulation.cpp:42-72; ParticleSystem::AllocateBoundaryParticles ->
+    pbf_set_boundary) == the Python generators + the oracle's boundary coupling; getSimParams()
+    (Simulation.h:76) holds SetupSimParams' values"""
     h, r, _, _, _ = scenes.sim_params_constants()
     assert h == np.float32(0.041528303) and r == np.float32(0.012331058)
     dump = tmp_path / "c2.bin"
     res = subprocess.run([str(RUN), "--scene", "c2", "--steps", "3", "--iters", "4", "--dump", str(dump)],
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
+    assert ("SimParams: effective_radius 0.0415283032 particle_radius 0.0123310583 epsilon 100 grid 64x64x64 "
+            "boundary 32000") in res.stdout, res.stdout
     pos, vel, _ = read_dump(dump)
     p, ipos, mass, cols, bpos, bm = scenes.c2_reference_cuda_scene(iterations=4)
     assert pos.shape == ipos.shape

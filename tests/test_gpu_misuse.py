@@ -30,7 +30,7 @@ def test_calls_out_of_order_and_bad_arguments_are_refused_and_the_ctx_survives()
                  lambda: g.finalize_stage(1, DT)):          # no neighbour table yet
         with pytest.raises(PbfError) as e:
             call()
-        assert e.value.code == B.PBF_ERR_INVALID and "pbf_build_grid" in str(e.value) or "neighbour table" in str(e.value)
+        assert e.value.code == B.PBF_ERR_INVALID and ("pbf_build_grid" in str(e.value) or "neighbour table" in str(e.value))
     with pytest.raises(PbfError) as e:
         g.set_colliders(list(cols) * 8)                     # > PBF_MAX_COLLIDERS
     assert e.value.code == B.PBF_ERR_INVALID

@@ -103,3 +103,76 @@ def test_noalloc_rejects_sizes_beyond_its_scratch_and_handles_empty_input():
                                        C.c_void_p(start.data_ptr()), 0, None) == B.PBF_OK
     torch.cuda.synchronize()
     assert int(start.abs().sum().item()) == 0
+
+
+def _call(lib, d_xyz, n, grid, origin, spacing, d_key, d_sid, d_start, stream):
+    gd = (C.c_int32 * 3)(*grid)
+    go = (C.c_int32 * 3)(*origin)
+    return lib.pbf_build_cells_noalloc(C.c_void_p(d_xyz.data_ptr()), n, C.byref(gd), C.byref(go), C.c_float(spacing),
+                                       C.c_void_p(d_key.data_ptr()), C.c_void_p(d_sid.data_ptr()),
+                                       C.c_void_p(d_start.data_ptr()), 0, C.c_void_p(stream))
+
+
+def test_noalloc_call_is_capturable_into_a_hip_graph_and_replays_on_new_inputs():
+    """the callers the entry point is for: under stream capture.  One warm-up call per device happens
+    OUTSIDE capture (the first call resolves the scratch array's address, which makes the runtime load
+    the code object: include/pbf.h says so); after that the call is memsets and kernel launches on the
+    caller's stream and nothing else -- captured once, replayed on two different inputs, each replay
+    equal to pbf_build_grid + pbf_get_cells."""
+    import torch
+    lib = B.load_library()
+    dev = torch.device("cuda", 0)
+    n, grid, origin, spacing = 60_000, (32, 24, 40), (-2, 0, -3), 0.5
+    ncell = int(np.prod(grid))
+    d_xyz = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+    d_key = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_sid = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_start = torch.zeros(ncell + 1, dtype=torch.int32, device=dev)
+    assert _call(lib, d_xyz, 0, grid, origin, spacing, d_key, d_sid, d_start,
+                 torch.cuda.current_stream().cuda_stream) == B.PBF_OK          # warm-up, not captured
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        rc = _call(lib, d_xyz, n, grid, origin, spacing, d_key, d_sid, d_start, torch.cuda.current_stream().cuda_stream)
+    assert rc == B.PBF_OK, lib.pbf_last_error(None)
+    for seed in (7, 8):
+        pos = scattered(n, -1.0, 15.0, seed)
+        d_xyz.copy_(torch.from_numpy(pos))
+        for t in (d_key, d_sid, d_start):
+            t.fill_(-1)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        want = ctx_cells(pos, grid, origin, spacing)
+        got = (d_key.cpu().numpy().view(np.uint32), d_sid.cpu().numpy().view(np.uint32),
+               d_start.cpu().numpy().view(np.uint32))
+        for name, w, g in zip(("cell_key", "sorted_id", "cell_start"), want, got):
+            assert np.array_equal(w, g), f"replay with seed {seed}: {name} differs from pbf_build_grid's"
+
+
+def test_noalloc_worst_case_every_particle_in_one_cell_stays_bounded():
+    """the rank-by-index pass is O(cell occupancy) per particle and this entry point has no crowd
+    limit: its particle limit IS the bound.  All 2^20 particles at one point = 2^40 compare steps;
+    the call must still finish in seconds and give the right answer (index order)."""
+    import time
+    import torch
+    lib = B.load_library()
+    dev = torch.device("cuda", 0)
+    n, grid = 1 << 20, (8, 8, 8)
+    d_xyz = torch.full((n, 3), 3.25, dtype=torch.float32, device=dev)
+    d_key = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_sid = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_start = torch.zeros(8 * 8 * 8 + 1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    assert _call(lib, d_xyz, n, grid, (0, 0, 0), 1.0, d_key, d_sid, d_start,
+                 torch.cuda.current_stream().cuda_stream) == B.PBF_OK
+    torch.cuda.synchronize()
+    took = time.perf_counter() - t0
+    print(f"2^20 particles in one cell: {took:.2f} s")
+    assert took < 30.0
+    assert torch.equal(d_sid, torch.arange(n, dtype=torch.int32, device=dev))
+    key = (3 * 8 + 3) * 8 + 3
+    start = d_start.cpu().numpy()
+    assert (start[:key + 1] == 0).all() and (start[key + 1:] == n).all()

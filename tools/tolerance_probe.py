@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Measurement for DESIGN.md section 3: a library built with -DPBF_EXP_FP32 (pair geometry, W, grad W
+"""Measurement for DESIGN.md section 3: a library built by tools/build_fp32_probe.py (pair geometry, W, grad W
 and s_corr in fp32, hardware square root) against the CPU oracle, north_star's single-step bar
 (1e-5 relative on positions AND velocities) and the 200-step statistics bar, plus its speed.
     python tools/tolerance_probe.py ab/libfp32.so

@@ -612,24 +612,36 @@ def main():
     if world == 1 and not a.no_sizes and not a.block:
         sizes = {}
         torch.cuda.empty_cache()
-        for name, blk in (("C2_64k", (40, 40, 40)), ("C4_16m_one_gpu", (256, 250, 250))):
-            q, qpos, qmass, qcols = scenes.dam_break(*blk, iterations=a.iters)
+        # C5's scene (64 M particles = 8 M per GPU on eight GPUs, XSPH 0.01 + vorticity 2e-6) on ONE GPU: it fits
+        # (about 35 GiB of the 288), so the weak-scaling configuration has a measured one-GPU figure of the
+        # whole scene beside it
+        for name, blk, visc in (("C2_64k", (40, 40, 40), None), ("C4_16m_one_gpu", (256, 250, 250), None),
+                                ("C5_64m_one_gpu", (1600, 200, 200), (0.01, 2e-6))):
+            kw = {} if visc is None else {"xsph_c": visc[0], "vorticity_eps": visc[1]}
+            q, qpos, qmass, qcols = scenes.dam_break(*blk, iterations=a.iters, **kw)
             qpos, _ = shuffled(qpos, not a.no_shuffle)
-            g = PbfContext(q, device=local)
+            try:
+                g = PbfContext(q, device=local)
+            except Exception as e:  # noqa: BLE001 -- a smaller GPU: say so, keep the line
+                sizes[name] = {"error": str(e)}
+                continue
             g.upload(qpos, uniform_mass=qmass)
             g.set_colliders(qcols)
-            for _ in range(10):
+            k_warm, k_time = (10, 20) if qpos.shape[0] <= 20_000_000 else (5, 10)
+            for _ in range(k_warm):
                 g.step(DT)
             g.sync()
             t0 = time.perf_counter()
-            for _ in range(20):
+            for _ in range(k_time):
                 g.step(DT)
             g.sync()
-            t = (time.perf_counter() - t0) / 20
+            t = (time.perf_counter() - t0) / k_time
             st = g.stats().as_dict()
             sizes[name] = {"workload": f"{blk[0]}x{blk[1]}x{blk[2]} dam-break block ({qpos.shape[0]} particles), "
-                                       f"{a.iters} iterations", "ms_per_step": t * 1e3, "value": qpos.shape[0] / t,
-                           "steps": 20, "warmup": 10, "mean_neighbors": st["mean_neighbor_count"],
+                                       f"{a.iters} iterations" + ("" if visc is None else f", XSPH {visc[0]} + vorticity {visc[1]}"),
+                           "ms_per_step": t * 1e3, "value": qpos.shape[0] / t,
+                           "steps": k_time, "warmup": k_warm, "mean_neighbors": st["mean_neighbor_count"],
+                           "mean_abs_C": st["mean_abs_C"], "max_speed": st["max_speed"],
                            "nonfinite": st["nonfinite"], "neighbor_overflow": st["neighbor_overflow"]}
             g.close()
             del g, qpos

@@ -100,13 +100,14 @@ def test_fused_halo_exchange_mirrors_the_boundary_planes():
     assert np.isfinite(ra).all()
 
 
-def _native_rank(rank, world, uid, p, pos, mass, cols, vel, planes, layers, steps, out, errs, rebalance):
+def _native_rank(rank, world, uid, p, pos, mass, cols, vel, planes, layers, steps, out, errs, rebalance,
+                 headroom=3.0):
     try:
         import torch
         from fluidsimulation_amd import slab as S
         torch.cuda.set_device(0)
         with torch.cuda.stream(torch.cuda.Stream()):
-            q = S.rank_local_params(p, pos, planes, rank, world, headroom=3.0, ghost_layers=layers)
+            q = S.rank_local_params(p, pos, planes, rank, world, headroom=headroom, ghost_layers=layers)
             b = S.HipSlabBackend(q, cols, mass, planes[rank], planes[rank + 1], device=0, ghost_layers=layers)
             S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
                        p.grid_spacing, vel=vel)
@@ -322,6 +323,66 @@ def test_c5_two_native_slabs_of_8m_particles_with_xsph_and_vorticity_equal_one_c
     assert rec.shape[0] == n
     order = np.argsort(S.record_ids(rec))
     assert np.array_equal(rec[order, 0:3], p1) and np.array_equal(rec[order, 4:7], v1)
+
+
+def test_c5_64m_particles_eight_native_slabs_of_8m_with_xsph_and_vorticity_equal_one_ctx():
+    """C5 in its REAL shape (BASELINE config 5: 64 M particles, 8 M per GPU, XSPH c = 0.01 + vorticity
+    confinement): the 1600x200x200 block as eight slabs of 8 000 000 particles, eight rank threads
+    stepping pbf_slab_step over the loopback transport on this one GPU (288 GB holds all of it),
+    against ONE ctx on the whole 64 M scene -- bit-identical after two sub-steps, viscosity stages
+    included; plus the size-independent health checks."""
+    import threading
+    import torch
+    from fluidsimulation_amd import slab as S
+    p, pos, mass, cols = scenes.dam_break(1600, 200, 200, iterations=4, xsph_c=0.01, vorticity_eps=2e-6)
+    n = pos.shape[0]
+    assert n == 64_000_000
+    steps, world, layers = 2, 8, 2
+    free0 = torch.cuda.mem_get_info(0)[0]
+    g = PbfContext(p, device=0)
+    used_one_ctx = free0 - torch.cuda.mem_get_info(0)[0]
+    g.upload(pos, uniform_mass=mass)
+    g.set_colliders(cols)
+    for _ in range(steps):
+        g.step(DT)
+    g.sync()
+    st = g.stats()
+    assert st.n == n and st.nonfinite == 0 and st.neighbor_overflow == 0
+    assert 15.0 < st.mean_neighbor_count < 30.0 and st.max_neighbor_count <= 64
+    p1, v1, _ = g.download()
+    assert float(np.abs(v1).max()) > 0.0
+    g.close()
+    del g
+    torch.cuda.empty_cache()
+    planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    owned = np.bincount(np.searchsorted(planes[1:-1], S.cell_x(pos[:, 0], p.grid_spacing), side="right"),
+                        minlength=world)
+    assert owned.min() > 7_500_000 and owned.max() < 8_500_000, owned     # 8 M per slab, up to the plane snapping
+    uid = RcclComm.local_id()
+    out, errs = {}, []
+    vel = np.zeros_like(pos)
+    ts = [threading.Thread(target=_native_rank, args=(r, world, uid, p, pos, mass, cols, vel, planes, layers,
+                                                      steps, out, errs, False, 1.25)) for r in range(world)]
+    import time
+    for t in ts:
+        t.start()
+    low, t_end = free0, time.time() + 900
+    while any(t.is_alive() for t in ts) and time.time() < t_end:    # high-water mark of the eight slab ctxs
+        low = min(low, torch.cuda.mem_get_info(0)[0])
+        time.sleep(0.02)
+    for t in ts:
+        t.join(timeout=10)
+    assert not errs, errs
+    print(f"C5 64 M: one ctx holds {used_one_ctx / 2**30:.1f} GiB of HBM; high-water mark of the eight slab ctxs + "
+          f"exchange buffers {(free0 - low) / 2**30:.1f} GiB")
+    ids = np.concatenate([S.record_ids(out[r]) for r in range(world)])
+    assert ids.shape[0] == n
+    order = np.argsort(ids)
+    del ids
+    for col, want in ((slice(0, 3), p1), (slice(4, 7), v1)):
+        got = np.concatenate([out[r][:, col] for r in range(world)], axis=0)[order]
+        assert np.array_equal(got, want)
+        del got
 
 
 def test_c4_eight_native_slabs_of_2m_particles_equal_one_ctx():

@@ -133,6 +133,9 @@ def parse():
                     help="ghost cell planes per slab side for N>1; 0 = time 4 (one halo refresh per sub-step) and "
                          "2 (three, half the ghost particles) on this machine's links before the run and keep "
                          "the faster; results are bit-identical either way")
+    ap.add_argument("--overlap", action="store_true",
+                    help="with --ghost-layers L >= 2: overlap the ghost refresh with the interior lambda sweep "
+                         "(pbf_slab_set_overlap); without --ghost-layers it is one of the timed candidates")
     ap.add_argument("--evolved-steps", type=int, default=2000,
                     help="N=1: after the BASELINE window, carry the same scene on until it has taken this many "
                          "sub-steps (the collapsing dam break) and time it again -> `evolved` (0 = skip)")
@@ -303,7 +306,7 @@ def multi_gpu_extras(a, sim, rank, world, local, time_steps):
         s, err = None, None
         try:
             s = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=layers,
-                               comm=shared, transport="torch" if shared is None else "auto")
+                               comm=shared, transport="torch" if shared is None else "auto", overlap=sim.overlap)
         except Exception as e:  # noqa: BLE001  (rank-local: allocation, capacity)
             err = f"rank {rank}: {e}"
         if not agree(err is None):
@@ -481,25 +484,36 @@ def main():
 
         layers, tuning = a.ghost_layers, None
         if layers > 0:
-            sim = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=layers)
+            sim = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=layers,
+                                 overlap=a.overlap)
         else:
-            # the trade between ghost work and exchange rounds depends on the links: measure it here.
-            # Both candidates share one communicator; the slower one is dropped, the faster carries on.
-            first = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=4)
-            shared = getattr(first.group.exchange, "comm", None)
-            second = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=2,
-                                    comm=shared, transport="torch" if shared is None else "auto")
-            tuning = {}
-            for cand in (first, second):
+            # The trade between ghost work, exchange rounds and hidden link time depends on the links:
+            # measure it here, before the run.  Candidates: ghost depth 4 (one refresh per sub-step), 2
+            # (three, half the ghost particles), 2 with the refresh overlapped with the interior lambda
+            # sweep (native step only), 1 (lambda exchanged too, a quarter of the ghost particles).  All
+            # share one communicator; the fastest carries on, the others are dropped.  Results are
+            # bit-identical for every candidate (tests/test_gpu_comm.py, tests/test_gpu_slab.py).
+            cands, shared, tuning = [], None, {}
+            for L, ov in ((4, False), (2, False), (2, True), (1, False)):
+                s_ = SlabSimulation(p, pos, mass, cols, rank=rank, world=world, device=local, ghost_layers=L,
+                                    overlap=ov, comm=shared, transport="auto" if (shared is not None or not cands) else "torch")
+                if not cands:
+                    shared = getattr(s_.group.exchange, "comm", None)
+                if ov and not s_.overlap:      # no native step (rehearsal over gloo): nothing to overlap
+                    del s_
+                    continue
+                cands.append(s_)
+            for cand in cands:
                 for _ in range(5):
                     cand.step(DT)
-                tuning[cand.ghost_layers] = time_steps(cand.step, cand.sync, 15)
-            layers = min(tuning, key=tuning.get)
-            sim, loser = (first, second) if layers == first.ghost_layers else (second, first)
-            loser.sync()
-            if sim is second and shared is not None:   # the communicator now belongs to the survivor
-                first.owns_comm, second.owns_comm = False, True
-            del loser
+                tuning[f"L{cand.ghost_layers}" + ("+overlap" if cand.overlap else "")] = time_steps(cand.step, cand.sync, 15)
+            best = min(range(len(cands)), key=lambda k: list(tuning.values())[k])
+            sim = cands[best]
+            layers = sim.ghost_layers
+            for k, cand in enumerate(cands):
+                cand.sync()
+                cand.owns_comm = (k == best) and shared is not None   # the communicator now belongs to the survivor
+            cands = None
         n_total = pos.shape[0]
         stepper = sim.step
         syncer = sim.sync
@@ -508,7 +522,7 @@ def main():
         ranks_seen["pbf_comm_world"] = int(comm.world) if comm is not None and hasattr(comm, "world") else None
         workload = (f"{scene_nx}x{block[1]}x{block[2]} dam-break block ({n_total} particles) in "
                     f"{world} x-slabs, {a.iters} solver iterations, dt=5e-4")
-        parallelism = f"slab{world}, {layers} ghost layers" + \
+        parallelism = f"slab{world}, {layers} ghost layers" + (" + overlapped refresh" if sim.overlap else "") + \
             (f" (picked from ms/sub-step {({k: round(v * 1e3, 4) for k, v in tuning.items()})})" if tuning else "") + \
             f", transport {sim.transport}"
 

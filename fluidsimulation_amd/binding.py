@@ -205,6 +205,7 @@ SYMBOLS = [
     "pbf_set_distance_constraints", "pbf_project_constraints", "pbf_get_constraint_lambdas",
     "pbf_comm_local_id", "pbf_slab_attach", "pbf_slab_step", "pbf_slab_owned_count",
     "pbf_slab_append_owned_host", "pbf_slab_export_host", "pbf_build_cells_noalloc", "pbf_slab_rebalance",
+    "pbf_slab_set_overlap",
 ]
 
 _lib = None
@@ -288,6 +289,7 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_comm_local_id.argtypes = [vp]
     lib.pbf_slab_attach.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32]
     lib.pbf_slab_step.argtypes = [vp, C.c_float]
+    lib.pbf_slab_set_overlap.argtypes = [vp, C.c_int32]
     lib.pbf_slab_owned_count.argtypes = [vp]
     lib.pbf_slab_rebalance.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.c_int32,
                                        C.POINTER(C.c_int32)]
@@ -607,6 +609,10 @@ class PbfContext:
     def slab_attach(self, comm: "RcclComm", left: int, right: int, max_records: int = 0):
         self._ck(self.lib.pbf_slab_attach(self._h, comm._h, left, right, max_records))
         self._comm = comm   # keep the communicator alive as long as the ctx uses it
+
+    def slab_set_overlap(self, on: bool):
+        """ghost refresh overlapped with the interior lambda sweep (pbf_slab_step; results do not change)"""
+        self._ck(self.lib.pbf_slab_set_overlap(self._h, 1 if on else 0))
 
     def slab_step(self, dt):
         self._ck(self.lib.pbf_slab_step(self._h, C.c_float(dt)))

@@ -154,6 +154,9 @@ struct pbf_ctx {
     uint32_t *x_host_counts = nullptr;  // pinned host mirror of the same size
     uint32_t *x_hist = nullptr, *x_host_hist = nullptr;   // re-balancing: (1 + world) plane histograms
     uint32_t x_hist_planes = 0;
+    bool overlap = false;               // pbf_slab_set_overlap
+    hipStream_t xstream = nullptr;      // second stream of the overlapped ghost refresh (created on demand)
+    hipEvent_t x_packed = nullptr, x_arrived = nullptr;
     bool owns_stream = true;
     bool uniform = false;      // every particle has uniform_mass (no per-neighbour mass gather)
     float uniform_mass = 0.f;
@@ -422,6 +425,15 @@ void free_link(pbf_ctx* c) {
     c->x_hist_planes = 0;
     c->link_comm = nullptr;
     c->link_max = 0;
+}
+
+void free_overlap(pbf_ctx* c) {
+    if (c->x_packed) (void)hipEventDestroy(c->x_packed);
+    if (c->x_arrived) (void)hipEventDestroy(c->x_arrived);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
+    c->x_packed = c->x_arrived = nullptr;
+    c->xstream = nullptr;
+    c->overlap = false;
 }
 
 void free_constraints(pbf_ctx* c) {

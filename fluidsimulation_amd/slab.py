@@ -558,7 +558,7 @@ class SlabSimulation:
 
     def __init__(self, params: PbfParams, pos, mass, colliders, rank, world, device=0, vel=None,
                  headroom=1.5, rebalance_every=0, ghost_layers=GHOST_LAYERS, transport="auto", native_step=True,
-                 comm=None):
+                 comm=None, overlap=False):
         """comm: an RcclComm of this rank to share with other SlabSimulations of the same group (it
         stays the caller's to close); None = create one when the transport asks for it"""
         import torch.distributed as dist
@@ -596,6 +596,10 @@ class SlabSimulation:
             self.backend.ctx.slab_attach(exchange.comm, -1 if rank == 0 else rank - 1,
                                          -1 if rank == world - 1 else rank + 1, self.backend.max_records)
             self.transport = "rccl (C ABI, native sub-step)"
+            if overlap:
+                self.backend.ctx.slab_set_overlap(True)
+                self.transport += ", ghost refresh overlapped with the interior lambda sweep"
+        self.overlap = bool(overlap and self.native)
         self.ctx = self.backend.ctx
         # global cell planes the re-balancing histograms cover: the tank, or the initial block +- 64
         if params.container_enabled:

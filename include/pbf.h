@@ -412,6 +412,14 @@ int pbf_slab_export_host(pbf_ctx* ctx, float* records, uint32_t max_records, uin
 int pbf_slab_attach(pbf_ctx* ctx, pbf_comm* comm, int32_t left_rank, int32_t right_rank,
                     uint32_t max_records);
 int pbf_slab_step(pbf_ctx* ctx, float dt);
+/* Overlap of the ghost refresh with the lambda sweep it precedes (pbf_slab_step, ghost_layers >= 2): the
+ * pack runs on the ctx stream, the grouped send / receive and the unpack on a second stream of the ctx,
+ * the sweep of the interior cell planes (which read no ghost) meanwhile on the ctx stream, and the sweeps
+ * of the two edge windows behind an event of the second stream.  Costs two more launches and two event
+ * waits per refresh and hides the link time of the refresh; which is faster depends on the links
+ * (bench.py --gpus N times both before the run).  Results do not depend on it.  Every rank of the
+ * communicator must use the same setting only for speed, not for correctness.  Default: off. */
+int pbf_slab_set_overlap(pbf_ctx* ctx, int32_t on);
 /* Collective re-balancing between sub-steps (every rank of the communicator calls it with the same
  * arguments): the per-x-plane counts of the owned particles of all ranks are gathered on every rank
  * (cell planes [x_first, x_first + n_planes), n_planes <= 4096; particles outside count in the end

@@ -60,6 +60,9 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     assert d["ranks_seen"]["all_reduce_of_ones"] == 2 and len(d["ranks_seen"]["devices"]) == 2
     assert d["config"]["particles"] == 2 * 24 * 20 * 20
     assert "slab2" in d["config"]["parallelism"] and "picked from" in d["config"]["parallelism"]
+    # the ghost-depth candidates timed before the run (the overlapped refresh needs the native step, i.e. nccl)
+    for cand in ("'L4'", "'L2'", "'L1'"):
+        assert cand in d["config"]["parallelism"], d["config"]["parallelism"]
     assert "REHEARSAL" in d["data"]
     # the secondary records of a multi-GPU launch: BASELINE's strong (C4) and viscous weak (C5) scenes,
     # here at rehearsal sizes, each with its one-GPU reference time and an efficiency

@@ -101,7 +101,7 @@ def test_fused_halo_exchange_mirrors_the_boundary_planes():
 
 
 def _native_rank(rank, world, uid, p, pos, mass, cols, vel, planes, layers, steps, out, errs, rebalance,
-                 headroom=3.0):
+                 headroom=3.0, overlap=False):
     try:
         import torch
         from fluidsimulation_amd import slab as S
@@ -114,6 +114,8 @@ def _native_rank(rank, world, uid, p, pos, mass, cols, vel, planes, layers, step
             comm = RcclComm(uid, rank, world, 0)
             b.ctx.slab_attach(comm, -1 if rank == 0 else rank - 1, -1 if rank == world - 1 else rank + 1,
                               b.max_records)
+            if overlap:
+                b.ctx.slab_set_overlap(True)
             my_planes = list(planes)
             for s in range(steps):
                 b.ctx.slab_step(DT)
@@ -126,10 +128,12 @@ def _native_rank(rank, world, uid, p, pos, mass, cols, vel, planes, layers, step
         errs.append((rank, repr(e)))
 
 
-@pytest.mark.parametrize("world,layers,viscous,rebalance", [(2, 2, False, False), (3, 2, False, True),
-                                                          (3, 4, False, False), (2, 4, True, False),
-                                                          (2, 1, True, False)])
-def test_native_slab_step_over_loopback_equals_single_domain(world, layers, viscous, rebalance):
+@pytest.mark.parametrize("world,layers,viscous,rebalance,overlap",
+                         [(2, 2, False, False, False), (3, 2, False, True, False), (3, 4, False, False, False),
+                          (2, 4, True, False, False), (2, 1, True, False, False),
+                          # the ghost refresh overlapped with the interior lambda sweep (pbf_slab_set_overlap)
+                          (3, 2, False, True, True), (3, 4, False, False, True), (2, 2, True, False, True)])
+def test_native_slab_step_over_loopback_equals_single_domain(world, layers, viscous, rebalance, overlap):
     """pbf_slab_step (the native sub-step that runs over RCCL on the multi-GPU node) with `world`
     rank threads on this one GPU over the library's loopback transport (same matching rule and
     stream semantics as the RCCL path): bit-identical with the single-domain oracle"""
@@ -144,7 +148,7 @@ def test_native_slab_step_over_loopback_equals_single_domain(world, layers, visc
     uid = RcclComm.local_id()
     out, errs = {}, []
     ts = [threading.Thread(target=_native_rank, args=(r, world, uid, p, pos, mass, cols, vel, planes, layers,
-                                                      steps, out, errs, rebalance)) for r in range(world)]
+                                                      steps, out, errs, rebalance, 3.0, overlap)) for r in range(world)]
     for t in ts:
         t.start()
     for t in ts:

@@ -21,3 +21,4 @@ rm -rf "$OUT/trace" "$OUT"/pmc/*/   # the raw traces stay on the box
 echo "pmc ok"
 timeout -k 10 300 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; exit 1; }
 echo "bench ok"
+python3 tools/resource_usage.py "${TAG:-r03}" >/dev/null && echo "resource usage ok"

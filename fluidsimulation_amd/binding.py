@@ -205,7 +205,7 @@ SYMBOLS = [
     "pbf_set_distance_constraints", "pbf_project_constraints", "pbf_get_constraint_lambdas",
     "pbf_comm_local_id", "pbf_slab_attach", "pbf_slab_step", "pbf_slab_owned_count",
     "pbf_slab_append_owned_host", "pbf_slab_export_host", "pbf_build_cells_noalloc", "pbf_slab_rebalance",
-    "pbf_slab_set_overlap",
+    "pbf_slab_set_overlap", "pbf_slab_step_dem",
 ]
 
 _lib = None
@@ -290,6 +290,7 @@ def load_library(path: os.PathLike | None = None):
     lib.pbf_slab_attach.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32]
     lib.pbf_slab_step.argtypes = [vp, C.c_float]
     lib.pbf_slab_set_overlap.argtypes = [vp, C.c_int32]
+    lib.pbf_slab_step_dem.argtypes = [vp, C.c_float, C.POINTER(PbfDemParams)]
     lib.pbf_slab_owned_count.argtypes = [vp]
     lib.pbf_slab_rebalance.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.c_int32,
                                        C.POINTER(C.c_int32)]
@@ -616,6 +617,10 @@ class PbfContext:
 
     def slab_step(self, dt):
         self._ck(self.lib.pbf_slab_step(self._h, C.c_float(dt)))
+        self.n = int(self.lib.pbf_num_particles(self._h))
+
+    def slab_step_dem(self, dt, dem: "PbfDemParams"):
+        self._ck(self.lib.pbf_slab_step_dem(self._h, C.c_float(dt), C.byref(dem)))
         self.n = int(self.lib.pbf_num_particles(self._h))
 
     def slab_rebalance(self, planes, x_first: int, n_planes: int, max_move: int):

@@ -163,6 +163,7 @@ struct pbf_ctx {
     bool keyed = false;  // histogram of the live prd already accumulated (k_predict / k_slab_split) ...
     uint32_t keyed_count = 0;  // ... for the first keyed_count particles (pre-sort order)
     bool grid_valid = false;
+    bool slots_valid = false;   // slot_of / cell_start describe the live arrays (a sort without a neighbour table: the DEM path)
     int32_t iterations = 1;
     std::string err;
     // profiling
@@ -367,6 +368,7 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = t
     if (!with_neighbors) {
         c->keyed = false;
         c->grid_valid = false;   // cells are sorted, but there is no neighbour table
+        c->slots_valid = true;
         return PBF_OK;
     }
     if (n) {
@@ -396,6 +398,7 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = t
     }
     c->keyed = false;
     c->grid_valid = true;
+    c->slots_valid = true;
     return PBF_OK;
 }
 

@@ -412,6 +412,11 @@ int pbf_slab_export_host(pbf_ctx* ctx, float* records, uint32_t max_records, uin
 int pbf_slab_attach(pbf_ctx* ctx, pbf_comm* comm, int32_t left_rank, int32_t right_rank,
                     uint32_t max_records);
 int pbf_slab_step(pbf_ctx* ctx, float dt);
+/* The granular sub-step (pbf_step_dem) of this rank's slab, exchanges included; needs ghost_layers >= 2.
+ * Same collective failure behaviour as pbf_slab_step.  Every pass runs over owned + ghost particles; the
+ * ghost positions are refreshed from their owners whenever fewer than two exact ghost layers are left (a
+ * pass uses up one).  Bit-identical with pbf_step_dem on one ctx over the whole scene. */
+int pbf_slab_step_dem(pbf_ctx* ctx, float dt, const pbf_dem_params* dem);
 /* Overlap of the ghost refresh with the lambda sweep it precedes (pbf_slab_step, ghost_layers >= 2): the
  * pack runs on the ctx stream, the grouped send / receive and the unpack on a second stream of the ctx,
  * the sweep of the interior cell planes (which read no ghost) meanwhile on the ctx stream, and the sweeps

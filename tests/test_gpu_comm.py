@@ -101,7 +101,7 @@ def test_fused_halo_exchange_mirrors_the_boundary_planes():
 
 
 def _native_rank(rank, world, uid, p, pos, mass, cols, vel, planes, layers, steps, out, errs, rebalance,
-                 headroom=3.0, overlap=False):
+                 headroom=3.0, overlap=False, dem=None):
     try:
         import torch
         from fluidsimulation_amd import slab as S
@@ -118,7 +118,10 @@ def _native_rank(rank, world, uid, p, pos, mass, cols, vel, planes, layers, step
                 b.ctx.slab_set_overlap(True)
             my_planes = list(planes)
             for s in range(steps):
-                b.ctx.slab_step(DT)
+                if dem is not None:
+                    b.ctx.slab_step_dem(DT, dem)
+                else:
+                    b.ctx.slab_step(DT)
                 if rebalance and s == 2:      # every rank moves the same plane by one cell
                     my_planes[1] += 1
                     b.set_bounds(my_planes[rank], my_planes[rank + 1])
@@ -165,6 +168,76 @@ def test_native_slab_step_over_loopback_equals_single_domain(world, layers, visc
     assert rec.shape[0] == pos.shape[0]
     assert np.array_equal(rec[order, 0:3], op) and np.array_equal(rec[order, 4:7], ov)
     assert all(out[r].shape[0] > 0 for r in range(world))
+
+
+@pytest.mark.parametrize("world,layers,walls", [(3, 2, False), (2, 3, False), (2, 2, True)])
+def test_native_granular_slab_step_equals_single_domain(world, layers, walls):
+    """pbf_slab_step_dem: the PBD granular / DEM sub-step under the slab
+    decomposition -- rank threads over the loopback transport, jittered overlapping grains with random
+    velocities (so grains migrate and contacts cross the cuts), optionally on boundary-particle walls --
+    bit-identical with the single-domain oracle's step_dem.  PARITY UNPINNED like pbf_step_dem itself."""
+    import threading
+    from fluidsimulation_amd import binding as B
+    from fluidsimulation_amd import slab as S
+    from oracle import pyoracle
+    h, r, _, _, _ = scenes.sim_params_constants()
+    rng = np.random.default_rng(23)
+    if walls:
+        p, pos, mass, cols, bpos, bm = scenes.boundary_tank(40, 8, 6, iterations=1)
+    else:
+        p, pos, mass, cols = scenes.dam_break(40, 8, 6, iterations=1)
+        p.container_enabled = 0
+        bpos = bm = None
+    pos = (pos + rng.uniform(-0.25, 0.25, pos.shape).astype(np.float32) * np.float32(r)).astype(np.float32)
+    vel = rng.normal(0, 0.8, pos.shape).astype(np.float32)
+    dem = B.dem_params(float(r), 1.0, 0.75, 3)
+    steps = 8
+    planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    uid = RcclComm.local_id()
+    out, errs = {}, []
+
+    def rank_main(rank):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                q = S.rank_local_params(p, pos, planes, rank, world, headroom=3.0, ghost_layers=layers)
+                b = S.HipSlabBackend(q, cols, mass, planes[rank], planes[rank + 1], device=0, ghost_layers=layers)
+                if bpos is not None:
+                    b.ctx.set_boundary(bpos, uniform_mass=bm)
+                S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
+                           p.grid_spacing, vel=vel)
+                comm = RcclComm(uid, rank, world, 0)
+                b.ctx.slab_attach(comm, -1 if rank == 0 else rank - 1, -1 if rank == world - 1 else rank + 1,
+                                  b.max_records)
+                with pytest.raises(PbfError):          # the single-ctx entry point says where to go
+                    b.ctx.step_dem(DT, dem)
+                for _ in range(steps):
+                    b.ctx.slab_step_dem(DT, dem)
+                b.sync()
+                out[rank] = b.export()
+        except BaseException as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=rank_main, args=(r_,)) for r_ in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs
+    rec = np.concatenate([out[r_] for r_ in range(world)], axis=0)
+    order = np.argsort(S.record_ids(rec))
+    o = pyoracle.Oracle(p)
+    o.upload(pos, vel=vel, uniform_mass=mass)
+    o.set_colliders(cols)
+    if bpos is not None:
+        o.set_boundary(bpos, uniform_mass=bm)
+    for _ in range(steps):
+        o.step_dem(DT, dem)
+    op, ov, _, _ = o.download()
+    assert rec.shape[0] == pos.shape[0] and all(out[r_].shape[0] > 0 for r_ in range(world))
+    assert np.array_equal(rec[order, 0:3], op) and np.array_equal(rec[order, 4:7], ov)
+    assert np.abs(op - pos).max() > 1e-4
 
 
 def test_native_slab_sweep_windows_fall_back_when_cells_wrap():

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential run of the native slab sub-step: W rank threads (loopback transport,
 one GPU) against the single-domain CPU oracle, bit for bit, over random block shapes, slab
-counts, ghost depths, iteration counts, velocities (migration), viscosity and a plane moved
-mid-run.    python tools/fuzz_slabs.py [cases] [seed]"""
+counts, ghost depths, iteration counts, velocities (migration), viscosity, a plane moved
+mid-run, the overlapped ghost refresh (pbf_slab_set_overlap) and the granular sub-step
+(pbf_slab_step_dem).    python tools/fuzz_slabs.py [cases] [seed]"""
 import sys, threading
 from pathlib import Path
 import numpy as np
@@ -59,6 +60,15 @@ def one_case(rng):
         o.close()
         ok = np.array_equal(gids, ids) and np.array_equal(gpos, op) and np.array_equal(gvel, ov)
         return ok, dict(desc0, path="python")
+    overlap = bool(rng.random() < 0.4)
+    dem = None
+    if layers >= 2 and rng.random() < 0.25:      # the granular sub-step: overlapping grains, no container clamp
+        from fluidsimulation_amd import binding as B
+        r_ = float(scenes.sim_params_constants()[1])
+        dem = B.dem_params(r_, float(rng.choice([0.5, 1.0])), 0.75, int(rng.integers(0, 5)))
+        p.container_enabled = 0
+        pos = (pos + rng.uniform(-0.25, 0.25, pos.shape).astype(np.float32) * np.float32(r_)).astype(np.float32)
+        rebalance_at = -1
     uid = RcclComm.local_id()
     out, errs = {}, []
 
@@ -73,9 +83,14 @@ def one_case(rng):
                 comm = RcclComm(uid, rank, world, 0)
                 b.ctx.slab_attach(comm, -1 if rank == 0 else rank - 1, -1 if rank == world - 1 else rank + 1,
                                   b.max_records)
+                if overlap:
+                    b.ctx.slab_set_overlap(True)
                 mine = list(planes)
                 for s in range(steps):
-                    b.ctx.slab_step(DT)
+                    if dem is not None:
+                        b.ctx.slab_step_dem(DT, dem)
+                    else:
+                        b.ctx.slab_step(DT)
                     if s == rebalance_at:
                         mine[1] += 1
                         b.set_bounds(mine[rank], mine[rank + 1])
@@ -87,7 +102,8 @@ def one_case(rng):
     ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     [t.start() for t in ts]
     [t.join(timeout=300) for t in ts]
-    desc = dict(world=world, layers=layers, iters=iters, dims=(nx, ny, nz), steps=steps, rebalance_at=rebalance_at, **kw)
+    desc = dict(world=world, layers=layers, iters=iters, dims=(nx, ny, nz), steps=steps, rebalance_at=rebalance_at,
+                overlap=overlap, dem=None if dem is None else int(dem.iterations), **kw)
     if errs:
         return False, dict(desc, errors=errs)
     rec = np.concatenate([out[r] for r in range(world)], axis=0)
@@ -96,7 +112,10 @@ def one_case(rng):
     o.upload(pos, vel=vel, uniform_mass=mass)
     o.set_colliders(cols)
     for _ in range(steps):
-        o.step(DT)
+        if dem is not None:
+            o.step_dem(DT, dem)
+        else:
+            o.step(DT)
     op, ov, _, _ = o.download()
     o.close()
     ok = rec.shape[0] == pos.shape[0] and np.array_equal(rec[order, 0:3], op) and np.array_equal(rec[order, 4:7], ov)

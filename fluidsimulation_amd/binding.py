@@ -25,6 +25,7 @@ PBF_ERR_NOT_INITIALIZED = 6
 
 PBF_COLLIDER_AABB = 2   # Collider::ColliderTypes::AABB  (reference Collider.h:10-17)
 PBF_COLLIDER_PLANE = 4  # Collider::ColliderTypes::PLANE
+PBF_COLLIDER_HARD_BOX = 100  # the CUDA path's baked-in box (cuda_simulation.cu:473-511)
 
 PBF_RHO0_FIRST_FRAME_MEAN = 0
 PBF_RHO0_FIXED = 1
@@ -165,6 +166,17 @@ def aabb(mn, mx) -> PbfCollider:
     c.type = PBF_COLLIDER_AABB
     c.a[:] = [float(x) for x in mn]
     c.b[:] = [float(x) for x in mx]
+    return c
+
+
+def hard_box(mn, mx, boundary_damping=0.1) -> PbfCollider:
+    """integrate_pbd_d's wall response (cuda_simulation.cu:473-511) as a collider: clamp to the box (open
+    top), point the velocity component back inside, multiply the whole velocity by boundary_damping"""
+    c = PbfCollider()
+    c.type = PBF_COLLIDER_HARD_BOX
+    c.a[:] = [float(x) for x in mn]
+    c.b[:] = [float(x) for x in mx]
+    c.d = float(boundary_damping)
     return c
 
 

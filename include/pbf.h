@@ -47,13 +47,21 @@ enum {
 /* collider kinds: values of Collider::ColliderTypes (Collider.h:10-17) */
 enum {
     PBF_COLLIDER_AABB = 2,
-    PBF_COLLIDER_PLANE = 4
+    PBF_COLLIDER_PLANE = 4,
+    /* not a Collider class of the reference: the hard box its CUDA path bakes into integrate_pbd_d
+     * (cuda_simulation.cu:473-511; x, z in [-1, 1], y >= 0, boundary_damping 0.1 in the README scene) */
+    PBF_COLLIDER_HARD_BOX = 100
 };
 
 /* One collider, copied by value into the ctx (the reference borrows raw
  * Collider* from the app, Simulation.cpp:252-256).
  *   PLANE: a = normal, d = offset; hit iff dot(a, p*) <= d   (CollisionDetection.cpp:62-67)
- *   AABB : a = min, b = max;      hit iff strictly inside    (CollisionDetection.cpp:29-34) */
+ *   AABB : a = min, b = max;      hit iff strictly inside    (CollisionDetection.cpp:29-34)
+ *   HARD_BOX: a = min, b = max (b[1], the top, is not used: the box is open), d = boundary damping.  The CUDA
+ *          path's wall response, in its order (x >= b[0], x <= a[0], z >= b[2], z <= a[2], y <= a[1]): the
+ *          predicted coordinate is clamped to the wall, the velocity component is pointed back inside
+ *          (-+|v|) and the WHOLE velocity vector is multiplied by d; no re-prediction.  Parity unpinned
+ *          (CUDA-only code); checked against this repo's oracle. */
 typedef struct pbf_collider {
     int32_t type;
     float a[3];

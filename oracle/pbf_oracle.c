@@ -369,7 +369,8 @@ int orc_upload(orc_ctx* c, const float* pos, const float* vel, const float* mass
 int orc_set_colliders(orc_ctx* c, const pbf_collider* cols, uint32_t count) {
     if (!c || count > PBF_MAX_COLLIDERS || (count && !cols)) return PBF_ERR_INVALID;
     for (uint32_t i = 0; i < count; ++i)
-        if (cols[i].type != PBF_COLLIDER_PLANE && cols[i].type != PBF_COLLIDER_AABB)
+        if (cols[i].type != PBF_COLLIDER_PLANE && cols[i].type != PBF_COLLIDER_AABB &&
+            cols[i].type != PBF_COLLIDER_HARD_BOX)
             return PBF_ERR_INVALID;
     if (count) memcpy(c->colliders, cols, count * sizeof(pbf_collider));
     c->num_colliders = count;
@@ -449,6 +450,22 @@ static void on_collision(orc_ctx* c, int i, const pbf_collider* col, float dt) {
     np[0] = pr[0]; np[1] = pr[1]; np[2] = pr[2];
 }
 
+/* The box the reference's CUDA path bakes into integrate_pbd_d (cuda_simulation.cu:473-511), as a collider:
+ * clamp the predicted coordinate, point the velocity component back inside, damp the whole vector; the
+ * predicted position is not recomputed.  PARITY UNPINNED (CUDA-only). */
+static void hard_box(orc_ctx* c, int i, const pbf_collider* col) {
+    float* v = c->vel + 3 * i;
+    float* pr = c->pred + 3 * i;
+    const float damp = col->d;
+    if (pr[0] >= col->b[0]) { pr[0] = col->b[0]; v[0] = -fabsf(v[0]); v[0] *= damp; v[1] *= damp; v[2] *= damp; }
+    if (pr[0] <= col->a[0]) { pr[0] = col->a[0]; v[0] = fabsf(v[0]); v[0] *= damp; v[1] *= damp; v[2] *= damp; }
+    if (pr[2] >= col->b[2]) { pr[2] = col->b[2]; v[2] = -fabsf(v[2]); v[0] *= damp; v[1] *= damp; v[2] *= damp; }
+    if (pr[2] <= col->a[2]) { pr[2] = col->a[2]; v[2] = fabsf(v[2]); v[0] *= damp; v[1] *= damp; v[2] *= damp; }
+    if (pr[1] <= col->a[1]) { pr[1] = col->a[1]; v[1] = fabsf(v[1]); v[0] *= damp; v[1] *= damp; v[2] *= damp; }
+    float* np = c->newp + 3 * i;
+    np[0] = pr[0]; np[1] = pr[1]; np[2] = pr[2];
+}
+
 /* Simulation::CollisionDetection, Simulation.cpp:723-751 (serial in the reference;
  * particles are independent, so the loop order over i does not matter) */
 int orc_collision_detection(orc_ctx* c, float dt) {
@@ -458,6 +475,10 @@ int orc_collision_detection(orc_ctx* c, float dt) {
     for (int i = 0; i < n; ++i) {
         for (uint32_t j = 0; j < c->num_colliders; ++j) {
             const pbf_collider* col = &c->colliders[j];
+            if (col->type == PBF_COLLIDER_HARD_BOX) {
+                hard_box(c, i, col);
+                continue;
+            }
             const float* pr = c->pred + 3 * i;
             int hit = (col->type == PBF_COLLIDER_PLANE) ? orc_point_plane(pr, col->a, col->d)
                                                         : orc_point_aabb(pr, col->a, col->b);

@@ -66,6 +66,47 @@ def test_predict_and_collide_bit_exact():
     assert (np.abs(oq - free).max(axis=1) > 1e-3).sum() > 10
 
 
+def test_hard_box_collider_the_cuda_paths_wall_response_bit_exact():
+    """PBF_COLLIDER_HARD_BOX: the box the reference's CUDA path bakes into integrate_pbd_d
+    (cuda_simulation.cu:473-511: x, z in [-1, 1], y >= 0, whole-vector x boundary_damping 0.1) as a
+    selectable collider -- clamp, no re-prediction.  PARITY UNPINNED (CUDA-only code): held to this repo's
+    oracle bit for bit, first on one predict pass with fast particles, then over 40 sub-steps of the README
+    scene's fluid cube dropped into that box."""
+    from fluidsimulation_amd.binding import hard_box
+    p, pos, mass, _ = scenes.c1_lattice(6, 10, 6)
+    rng = np.random.default_rng(11)
+    vel = rng.normal(0, 900.0, pos.shape).astype(np.float32)
+    lo, hi = pos.min(axis=0) - 0.2, pos.max(axis=0) + 0.2
+    cols = [hard_box(lo, hi, 0.1)]
+    g, o = make_pair(p, pos, mass, cols, vel=vel)
+    g.predict(DT)
+    o.predict_positions(DT)
+    o.collision_detection(DT)
+    gp, gv, gq = g.download()
+    op, ov, oq, onew = o.download()
+    assert np.array_equal(gv, ov) and np.array_equal(gq, oq) and np.array_equal(gq, onew)
+    assert (oq[:, 0] >= lo[0]).all() and (oq[:, 0] <= hi[0]).all() and (oq[:, 1] >= lo[1]).all()
+    assert (oq[:, 2] >= lo[2]).all() and (oq[:, 2] <= hi[2]).all()
+    assert (oq[:, 1] > hi[1]).any()                       # the box is open at the top, as the reference's
+    hit = (oq[:, 0] == lo[0]) | (oq[:, 0] == hi[0]) | (oq[:, 1] == lo[1]) | (oq[:, 2] == lo[2]) | (oq[:, 2] == hi[2])
+    assert hit.sum() > 20
+    free_v = vel + np.float32(DT) * np.float32(-9.8) * np.array([0, 1, 0], np.float32)
+    assert (np.abs(ov[hit]).max(axis=1) <= 0.1 * np.abs(free_v[hit]).max(axis=1) + 1e-3).all()   # whole vector damped
+    # the README scene's cube (64 000 particles, Simulation.cpp:528-576) in the CUDA path's box
+    p2, pos2, m2, _cols, _b, _bm = scenes.c2_reference_cuda_scene(iterations=3)   # iterations = 3: Simulation.cpp:148
+    box = [hard_box((-1.0, 0.0, -1.0), (1.0, 1.0e9, 1.0), 0.1)]
+    g, o = make_pair(p2, pos2, m2, box)
+    for _ in range(40):
+        g.step(DT)
+        o.step(DT)
+    g.sync()
+    q, v, _ = g.download()
+    oq2, ov2, _, _ = o.download()
+    assert np.array_equal(q, oq2) and np.array_equal(v, ov2)
+    # the box acts on the PREDICTED positions: the solver's corrections may carry a particle a hair outside
+    assert np.isfinite(q).all() and q[:, 1].min() > -0.01 and np.abs(q[:, [0, 2]]).max() < 1.01
+
+
 def test_cells_sorted_order_neighbor_sets_bit_exact():
     p, pos, mass, cols = scenes.c1_lattice(8, 16, 8)
     pos = jitter(pos, 0.2)

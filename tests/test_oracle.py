@@ -692,3 +692,30 @@ def test_constraint_list_is_gauss_seidel_in_list_order():
     assert not np.allclose(out[0], out[1])
     assert abs(np.linalg.norm(out[0][2] - out[0][1]) - 2.0) < 1e-5   # the LAST constraint is satisfied
     assert abs(np.linalg.norm(out[1][1] - out[1][0]) - 2.0) < 1e-5
+
+
+def test_hard_box_collider_known_answers():
+    """PBF_COLLIDER_HARD_BOX (the box of the reference's CUDA integrate_pbd_d, cuda_simulation.cu:473-511),
+    by hand: particle 0 flies through x = +1 (clamped, v.x = -|v.x|, the whole vector x 0.1, no
+    re-prediction of y / z from the damped velocity), particle 1 through the floor y = 0."""
+    from fluidsimulation_amd import scenes
+    from fluidsimulation_amd.binding import hard_box
+    p, _pos, mass, _ = scenes.c1_lattice(2, 2, 2)
+    pos = np.array([[0.95, 0.5, 0.0], [0.0, 0.01, 0.0]], np.float32)
+    vel = np.array([[200.0, 10.0, -3.0], [1.0, -100.0, 2.0]], np.float32)
+    o = pyoracle.Oracle(p)
+    o.upload(pos, vel=vel, uniform_mass=mass)
+    o.set_colliders([hard_box((-1, 0, -1), (1, 9, 1), 0.1)])
+    dt = np.float32(0.0005)
+    o.predict_positions(float(dt))
+    o.collision_detection(float(dt))
+    _, v, q, qn = o.download()
+    vy0 = np.float32(10.0) + dt * np.float32(1.0 / mass) * (np.float32(mass) * np.float32(-9.8))
+    assert q[0, 0] == np.float32(1.0) and q[0, 1] == np.float32(0.5) + dt * vy0
+    assert q[0, 2] == np.float32(0.0) + dt * np.float32(-3.0)
+    assert v[0, 0] == np.float32(-200.0) * np.float32(0.1) and v[0, 1] == vy0 * np.float32(0.1)
+    assert v[0, 2] == np.float32(-3.0) * np.float32(0.1)
+    vy1 = np.float32(-100.0) + dt * np.float32(1.0 / mass) * (np.float32(mass) * np.float32(-9.8))
+    assert q[1, 1] == np.float32(0.0) and v[1, 1] == np.abs(vy1) * np.float32(0.1)
+    assert v[1, 0] == np.float32(1.0) * np.float32(0.1) and q[1, 0] == dt * np.float32(1.0)
+    assert np.array_equal(q, qn)

@@ -32,6 +32,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -142,6 +143,7 @@ struct pbf_ctx {
     std::vector<uint32_t> cons_order;                // level-ordered position -> list index
     struct ConsBatch { uint32_t first_level, n_levels, first, count; bool one_block; };
     std::vector<ConsBatch> cons_batches;
+    std::vector<uint32_t> cons_level_start_host;     // slab mode runs level by level (a ghost refresh after each)
     uint32_t cons_max_particle = 0;
     // native slab step (pbf_slab_attach / pbf_slab_step): exchange buffers owned by the ctx
     pbf_comm* link_comm = nullptr;
@@ -448,6 +450,7 @@ void free_constraints(pbf_ctx* c) {
     c->ncons = c->ncons_levels = 0;
     c->cons_order.clear();
     c->cons_batches.clear();
+    c->cons_level_start_host.clear();
 }
 
 void free_boundary(pbf_ctx* c) {
@@ -482,6 +485,11 @@ int check_flags(pbf_ctx* c) {
                         "arrangement -- or grid_dim is far too small for the scene; the sort and the neighbour "
                         "build, O(occupancy) per particle, were skipped from that sub-step on and the state is "
                         "undefined until the next upload");
+    if (f.unreachable_constraints)
+        return fail(c, PBF_ERR_INVALID,
+                    std::to_string(f.unreachable_constraints) + " distance constraint projection(s) of owned particles were "
+                    "skipped: the other endpoint lies beyond this slab's ghost planes (constraints must be shorter than "
+                    "ghost_layers cells along x)");
     if (f.neighbor_overflow)
         return fail(c, PBF_ERR_NEIGHBOR_OVERFLOW,
                     std::to_string(f.neighbor_overflow) + " particles exceed " + rows + " (largest count " +
@@ -501,9 +509,9 @@ extern "C" {
 #include "abi/lifecycle.inc"
 #include "abi/boundary.inc"
 #include "abi/substep.inc"
+#include "abi/constraints.inc"
 #include "abi/slab.inc"
 #include "abi/step.inc"
-#include "abi/constraints.inc"
 #include "abi/dem.inc"
 #include "abi/readback.inc"
 #include "abi/noalloc.inc"

@@ -299,7 +299,15 @@ int pbf_step_dem(pbf_ctx* ctx, float dt, const pbf_dem_params* dem);
  * share no particle (a constraint's level = 1 + the highest level of an earlier constraint on
  * either of its particles), executed level by level: every particle sees its constraints in list
  * order, so the result is the sequential Gauss-Seidel result bit for bit.  Particles are
- * addressed by ORIGINAL index; stiffness is clamped to [0, 1] (Constraint::setStiffness). */
+ * addressed by ORIGINAL index; stiffness is clamped to [0, 1] (Constraint::setStiffness).
+ * Slab mode (set the list after pbf_slab_set_bounds, the same list on every rank): the indices are the
+ * GLOBAL particle ids the slab's records carry; pbf_slab_step projects the list level by level between the
+ * solver iterations and the velocity update -- a constraint on every rank that holds both endpoints (owned
+ * or ghost), the ghost positions refreshed from their owners after every level (one exchange per level and
+ * solver iteration) -- bit-identical with one ctx over the whole scene.  A constraint whose endpoints are
+ * further apart along x than the ghost planes reach cannot be projected by the owner of an endpoint: it is
+ * counted on the device and the next pbf_slab_step fails on EVERY rank (PBF_ERR_INVALID).
+ * pbf_project_constraints itself refuses a slab ctx (it cannot refresh the ghost copies). */
 enum { PBF_CONSTRAINTS_PBD = 0, PBF_CONSTRAINTS_XPBD = 1 };  /* PBD_MODE, ConstraintSolver.h */
 typedef struct pbf_distance_constraint {
     uint32_t p0, p1;      /* m_particles[0], m_particles[1] */

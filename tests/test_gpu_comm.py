@@ -240,6 +240,115 @@ def test_native_granular_slab_step_equals_single_domain(world, layers, walls):
     assert np.abs(op - pos).max() > 1e-4
 
 
+@pytest.mark.parametrize("world,layers,mode,viscous", [(3, 2, 0, False), (2, 2, 1, False), (2, 3, 1, True), (3, 1, 1, False)])
+def test_native_slab_step_with_distance_constraints_equals_single_domain(world, layers, mode, viscous):
+    """distance constraints under the slab decomposition: every rank holds the
+    whole list (global particle ids), pbf_slab_step projects it level by level between the solver
+    iterations and the velocity update, with a refresh of the ghost positions after every level -- a
+    shuffled lattice of links, many of them across the slab cuts, particles migrating meanwhile --
+    bit-identical with the single-domain oracle's Gauss-Seidel sweep in list order, PBD and XPBD."""
+    import threading
+    from fluidsimulation_amd import slab as S
+    from oracle import pyoracle
+    from tests.slab_common import slab_scene
+    from tests.test_gpu_constraints import lattice_links
+    nx, ny, nz = 36, 5, 4
+    kw = dict(xsph_c=0.01, vorticity_eps=2e-6) if viscous else {}
+    p, pos, mass, cols, vel = slab_scene(nx=nx, ny=ny, nz=nz, iterations=2, vel_scale=1.5, **kw)
+    h, r, _, _, _ = scenes.sim_params_constants()
+    cons = lattice_links(nx, ny, nz, 2.0 * float(r), np.random.default_rng(9))
+    steps = 5
+    planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    crossing = sum(1 for c_ in cons if np.searchsorted(planes[1:-1], S.cell_x(pos[c_[0]:c_[0] + 1, 0], p.grid_spacing)[0], side="right")
+                   != np.searchsorted(planes[1:-1], S.cell_x(pos[c_[1]:c_[1] + 1, 0], p.grid_spacing)[0], side="right"))
+    assert crossing >= 10 * (world - 1)                  # links really straddle the cuts
+    uid = RcclComm.local_id()
+    out, errs = {}, []
+
+    def rank_main(rank):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                q = S.rank_local_params(p, pos, planes, rank, world, headroom=3.0, ghost_layers=layers)
+                b = S.HipSlabBackend(q, cols, mass, planes[rank], planes[rank + 1], device=0, ghost_layers=layers)
+                b.ctx.set_distance_constraints(cons, mode)        # global ids; after pbf_slab_set_bounds
+                S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
+                           p.grid_spacing, vel=vel)
+                comm = RcclComm(uid, rank, world, 0)
+                b.ctx.slab_attach(comm, -1 if rank == 0 else rank - 1, -1 if rank == world - 1 else rank + 1,
+                                  b.max_records)
+                with pytest.raises(PbfError):          # outside the native step the ghost copies cannot be refreshed
+                    b.ctx.project_constraints(DT)
+                for _ in range(steps):
+                    b.ctx.slab_step(DT)
+                b.sync()
+                out[rank] = b.export()
+        except BaseException as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=rank_main, args=(r_,)) for r_ in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs
+    rec = np.concatenate([out[r_] for r_ in range(world)], axis=0)
+    order = np.argsort(S.record_ids(rec))
+    o = pyoracle.Oracle(p)
+    o.upload(pos, vel=vel, uniform_mass=mass)
+    o.set_colliders(cols)
+    o.set_distance_constraints(cons, mode)
+    for _ in range(steps):
+        o.step(DT)
+    op, ov, _, _ = o.download()
+    assert rec.shape[0] == pos.shape[0] and all(out[r_].shape[0] > 0 for r_ in range(world))
+    assert np.array_equal(rec[order, 0:3], op) and np.array_equal(rec[order, 4:7], ov)
+
+
+def test_native_slab_constraint_beyond_the_ghost_planes_fails_on_every_rank():
+    """a constraint between particles many cell planes apart cannot be projected by a rank that holds only
+    one endpoint: counted on the device, carried in the sub-step's counter block, and the NEXT sub-step fails
+    on every rank with the same message -- never a silently missing constraint"""
+    import threading
+    from fluidsimulation_amd import slab as S
+    from tests.slab_common import slab_scene
+    world, layers = 2, 2
+    p, pos, mass, cols, vel = slab_scene(nx=40, ny=4, nz=4, iterations=1, vel_scale=0.0)
+    far = (0, pos.shape[0] - 1, 0.5, 0.5, 1e-7)          # first and last particle: one in each end slab
+    planes = S.split_planes(pos, p.grid_spacing, world, min_width=2 * layers + 1)
+    uid = RcclComm.local_id()
+    msgs, errs = {}, []
+
+    def rank_main(rank):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                q = S.rank_local_params(p, pos, planes, rank, world, headroom=3.0, ghost_layers=layers)
+                b = S.HipSlabBackend(q, cols, mass, planes[rank], planes[rank + 1], device=0, ghost_layers=layers)
+                b.ctx.set_distance_constraints([far], 1)
+                S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
+                           p.grid_spacing, vel=vel)
+                comm = RcclComm(uid, rank, world, 0)
+                b.ctx.slab_attach(comm, -1 if rank == 0 else rank - 1, -1 if rank == world - 1 else rank + 1,
+                                  b.max_records)
+                b.ctx.slab_step(DT)                     # the projection is skipped and counted
+                with pytest.raises(PbfError) as e:
+                    b.ctx.slab_step(DT)                 # ... and every rank learns of it here
+                msgs[rank] = str(e.value)
+        except BaseException as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=rank_main, args=(r_,)) for r_ in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errs, errs
+    assert msgs[0] == msgs[1] and "beyond the slab's ghost planes" in msgs[0] and "rank 0" in msgs[0]
+
+
 def test_native_slab_sweep_windows_fall_back_when_cells_wrap():
     """pbf_slab_step sweeps only the owned cell planes plus the ghost planes an iteration still
     needs -- a run of slots of the cell-sorted arrays, as long as no cell wraps around the

@@ -113,5 +113,8 @@ def test_constraint_errors_and_clearing():
     o.set_distance_constraints([])
     g.step(DT); o.step(DT)
     assert same(g, o)
+    # slab mode keeps the list (global ids; tests/test_gpu_comm.py) but projects it only inside pbf_slab_step
+    g.set_distance_constraints([(0, 1, 0.05, 1.0, 0.0)])
+    g.slab_set_bounds(0, 8, 2)
     with pytest.raises(PbfError):
-        g.slab_set_bounds(0, 8, 2) if g.set_distance_constraints([(0, 1, 0.05, 1.0, 0.0)]) is None else None
+        g.project_constraints(DT)

@@ -36,6 +36,10 @@ def one_case(rng):
         p.container_enabled = 0
     if rng.random() < 0.3:
         cols = list(cols) + [B.aabb((0.05, 0.0, 0.05), (0.15, 0.1, 0.2))]
+    if rng.random() < 0.2:       # the CUDA path's hard box (PBF_COLLIDER_HARD_BOX) in front of / behind the others
+        lo, hi = pos.min(axis=0), pos.max(axis=0)
+        box = B.hard_box(lo - rng.uniform(0.0, 0.02, 3), hi + rng.uniform(0.0, 0.02, 3), float(rng.choice([0.1, 0.5, 1.0])))
+        cols = [box] + list(cols) if rng.random() < 0.5 else list(cols) + [box]
     if rng.random() < 0.2:       # duplicates: coincident particles (distance 0)
         k = int(rng.integers(1, 4))
         pos[-k:] = pos[:k]

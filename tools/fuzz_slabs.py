@@ -69,6 +69,19 @@ def one_case(rng):
         p.container_enabled = 0
         pos = (pos + rng.uniform(-0.25, 0.25, pos.shape).astype(np.float32) * np.float32(r_)).astype(np.float32)
         rebalance_at = -1
+    cons, cmode = None, 0
+    if dem is None and rng.random() < 0.25:       # distance constraints across the cuts (global ids)
+        idx = lambda i, j, k: (i * ny + j) * nz + k
+        d_ = 2.0 * float(scenes.sim_params_constants()[1])
+        cons = []
+        for i in range(nx):
+            for j in range(ny):
+                for k in range(nz):
+                    if i + 1 < nx and rng.random() < 0.7: cons.append((idx(i, j, k), idx(i + 1, j, k), d_ * float(rng.uniform(0.8, 1.2)), 0.8, 1e-7))
+                    if j + 1 < ny and rng.random() < 0.5: cons.append((idx(i, j, k), idx(i, j + 1, k), 0.9 * d_, 0.6, 1e-6))
+        cons = [cons[t] for t in rng.permutation(len(cons))]
+        cmode = int(rng.integers(0, 2))
+        vel = (vel * np.float32(0.3)).astype(np.float32)      # the links must stay shorter than the ghost planes reach
     uid = RcclComm.local_id()
     out, errs = {}, []
 
@@ -78,6 +91,8 @@ def one_case(rng):
             with torch.cuda.stream(torch.cuda.Stream()):
                 q = S.rank_local_params(p, pos, planes, rank, world, headroom=3.0, ghost_layers=layers)
                 b = S.HipSlabBackend(q, cols, mass, planes[rank], planes[rank + 1], device=0, ghost_layers=layers)
+                if cons is not None:
+                    b.ctx.set_distance_constraints(cons, cmode)
                 S.populate(b, pos, mass, np.arange(pos.shape[0], dtype=np.uint32), planes[rank], planes[rank + 1],
                            p.grid_spacing, vel=vel)
                 comm = RcclComm(uid, rank, world, 0)
@@ -103,7 +118,8 @@ def one_case(rng):
     [t.start() for t in ts]
     [t.join(timeout=300) for t in ts]
     desc = dict(world=world, layers=layers, iters=iters, dims=(nx, ny, nz), steps=steps, rebalance_at=rebalance_at,
-                overlap=overlap, dem=None if dem is None else int(dem.iterations), **kw)
+                overlap=overlap, dem=None if dem is None else int(dem.iterations),
+                constraints=None if cons is None else (len(cons), cmode), **kw)
     if errs:
         return False, dict(desc, errors=errs)
     rec = np.concatenate([out[r] for r in range(world)], axis=0)
@@ -111,6 +127,8 @@ def one_case(rng):
     o = pyoracle.Oracle(p)
     o.upload(pos, vel=vel, uniform_mass=mass)
     o.set_colliders(cols)
+    if cons is not None:
+        o.set_distance_constraints(cons, cmode)
     for _ in range(steps):
         if dem is not None:
             o.step_dem(DT, dem)

@@ -62,3 +62,42 @@ def model(L):
 
 for l in (1, 2, 4, 8, 16):
     model(l)
+
+
+def aligned_model(level):
+    """one lane per particle, the walk re-synchronised at every change of dx (level 1: three segments) or
+    of (dx, dy) (level 2: nine segments): a wave pads each segment to its longest lane"""
+    cx = c[order]                                     # cell coordinates per slot
+    sect = slots = waves = instr = 0
+    for w0 in range(0, n - 64 + 1, 64 * 37):
+        sl = np.arange(w0, w0 + 64)
+        waves += 1
+        segs = []
+        for dx in (-1, 0, 1):
+            for dy in ((-1, 0, 1) if level == 2 else (None,)):
+                per_lane = []
+                for i in sl:
+                    js = lists[i, :cn[i]]
+                    m = (cx[js, 0] - cx[i, 0]) == dx
+                    if dy is not None:
+                        m &= (cx[js, 1] - cx[i, 1]) == dy
+                    per_lane.append(js[m])
+                segs.append(per_lane)
+        for per_lane in segs:
+            longest = max(len(a_) for a_ in per_lane)
+            trips = -(-longest // 4)
+            for t in range(trips):
+                for u in range(4):
+                    k = 4 * t + u
+                    a_ = np.array([pl[k] if k < len(pl) else i for pl, i in zip(per_lane, sl) if 4 * t < max(len(pl), 1) or True])
+                    act = np.array([4 * t < len(pl) for pl in per_lane])
+                    if act.any():
+                        sect += len(np.unique(a_[act] // 2)); instr += 1
+                slots += 64 * 4
+    npart = waves * 64
+    print(f"  aligned at every {'(dx, dy)' if level == 2 else 'dx'}: {sect / npart:6.2f} sectors, {instr / npart:5.2f} gather instr, "
+          f"{slots / npart:6.2f} pair slots per particle and sweep; {sect / max(instr, 1):.1f} sectors per gather")
+
+
+aligned_model(1)
+aligned_model(2)

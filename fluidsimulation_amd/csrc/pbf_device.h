@@ -159,6 +159,26 @@ __device__ __forceinline__ float sqrt_rn(float x) {
     return sqrtf(x);
 }
 
+// sqrt_rn for a squared distance whose root ONLY feeds the SPH kernel functions above: they map +inf and NaN
+// to the same zero weight / gradient (a failed support test; fmax(NaN, 0) = 0), so +inf may take the
+// rsq path, where it turns into NaN -- one comparison per pair instead of two in the VALU-bound sweeps.
+__device__ __forceinline__ float sqrt_rn_for_kernel(float x) {
+    if (x >= 1.2621774e-29f) {  // [2^-96, +inf]; NaN fails the test
+        float r = __builtin_amdgcn_rsqf(x);
+        float y = x * r;
+        float h = 0.5f * r;
+        float e = fmaf(-y, y, x);
+        y = fmaf(e, h, y);
+        return y;
+    }
+    return sqrtf(x);
+}
+
+// The x and y components of a float4 record as one register pair (they ARE one: a 16-byte load fills an
+// aligned quad), for v_pk_* arithmetic on both; every packed operation rounds each half like the scalar one.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f xy_of(const float4& v) { return v2f{v.x, v.y}; }
+
 // x^4 for a double that holds an fp32 value (the reference's pow(x, 4), Simulation.cpp:701,
 // where x = float / float): x*x has at most 48 significant bits and is exact in double, so
 // (x*x)*(x*x) rounds ONCE -- it is the correctly rounded x^4, which is what glibc's pow
@@ -263,22 +283,32 @@ __device__ __forceinline__ const uint32_t* nbr_win_table(const NbrWin& win, uint
     return t + ((i >> NBR_GROUP_SHIFT) - g0) * NBR_WIN_STRIDE;
 }
 
-// the four entries of the group of rows that starts at `rows` (uniform) for the lane at byte offset off
-__device__ __forceinline__ void nbr_load4(const char* __restrict__ rows, size_t row_bytes, uint32_t off,
-                                          uint32_t fmt, uint32_t i, const uint32_t* win_tbl, uint32_t (&jn)[4]) {
+// The rows are read with BUFFER loads: the descriptor holds the (uniform) address of the current group of
+// four rows, the lane's byte offset inside a row is loop-invariant, and row u of the group is the scalar
+// offset u * row_bytes -- so a row load costs no vector instruction for its address (global loads need a
+// 64-bit per-lane address: one v_lshl_add_u64 per load, ~5 % of a VALU-bound sweep's instruction time).
+// cap <= 2^28: off < row_bytes <= 2^30 and 3 * row_bytes + off < 2^32.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t nbr_rows_rsrc(const char* rows) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(rows), 0, 0xffffffffu, 0x00020000);
+}
+
+// the four entries of the group of rows behind `rsrc` for the lane at byte offset off, as BYTE offsets of
+// the neighbours' float4 records (slot << 4: the shift rides on the add that decodes the entry)
+__device__ __forceinline__ void nbr_load4(__amdgpu_buffer_rsrc_t rsrc, uint32_t row_bytes, uint32_t off,
+                                          uint32_t fmt, uint32_t i, const uint32_t* win_tbl, uint32_t (&jb)[4]) {
     if (fmt == NBR_REL16) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            jn[u] = (uint32_t)((int32_t)i + (int32_t)*reinterpret_cast<const int16_t*>(rows + u * row_bytes + off));
+            jb[u] = (i + (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, off, u * row_bytes, 0)) << 4;
     } else if (fmt == NBR_WIN16) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t e = *reinterpret_cast<const uint16_t*>(rows + u * row_bytes + off);
-            jn[u] = win_tbl[e >> 12] + (e & 0xfffu);
+            const uint32_t e = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, off, u * row_bytes, 0);
+            jb[u] = (win_tbl[e >> 12] + (e & 0xfffu)) << 4;
         }
     } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) jn[u] = *reinterpret_cast<const uint32_t*>(rows + u * row_bytes + off);
+        for (int u = 0; u < 4; ++u) jb[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, u * row_bytes, 0) << 4;
     }
 }
 
@@ -294,24 +324,23 @@ __device__ __forceinline__ void for_each_neighbor(uint32_t i, uint32_t count_wor
     const uint32_t rel16 = count_word >> NBR_FMT_SHIFT;   // the entry format
     const uint32_t cnt = count_word & NBR_COUNT_MASK;
     const uint32_t off = nbr_offset(i, rel16 != NBR_ABS32);
-    const size_t row_bytes = (size_t)cap * 4;
+    const uint32_t row_bytes = cap * 4u;
     const char* __restrict__ rows = reinterpret_cast<const char*>(nbr);   // uniform: row k0 of every particle
     const uint32_t* win_tbl = nbr_win_table(win, i, rel16, cap);
     uint32_t jn[4] = {0u, 0u, 0u, 0u};
-    if (cnt) nbr_load4(rows, row_bytes, off, rel16, i, win_tbl, jn);
+    if (cnt) nbr_load4(nbr_rows_rsrc(rows), row_bytes, off, rel16, i, win_tbl, jn);
     for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
-        const uint32_t j[4] = {jn[0], jn[1], jn[2], jn[3]};
+        const uint32_t jb[4] = {jn[0], jn[1], jn[2], jn[3]};
         float4 xj[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            // 32-bit byte offset (capacity <= 2^28): one shift, and the load takes the base from
-            // scalar registers, instead of a 64-bit address per gather
-            xj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + (j[u] << 4));
-        rows += 4 * row_bytes;
-        if (k0 + 4 < cnt) nbr_load4(rows, row_bytes, off, rel16, i, win_tbl, jn);
+            // 32-bit byte offset (capacity <= 2^28): the load takes the base from scalar registers
+            xj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + jb[u]);
+        rows += 4 * (size_t)row_bytes;
+        if (k0 + 4 < cnt) nbr_load4(nbr_rows_rsrc(rows), row_bytes, off, rel16, i, win_tbl, jn);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (k0 + u < cnt) f(j[u], xj[u]);
+            if (k0 + u < cnt) f(jb[u] >> 4, xj[u]);
     }
 }
 
@@ -328,24 +357,24 @@ __device__ __forceinline__ void for_each_neighbor2(uint32_t i, uint32_t count_wo
     const uint32_t rel16 = count_word >> NBR_FMT_SHIFT;   // the entry format
     const uint32_t cnt = count_word & NBR_COUNT_MASK;
     const uint32_t off = nbr_offset(i, rel16 != NBR_ABS32);
-    const size_t row_bytes = (size_t)cap * 4;
+    const uint32_t row_bytes = cap * 4u;
     const char* __restrict__ rows = reinterpret_cast<const char*>(nbr);
     const uint32_t* win_tbl = nbr_win_table(win, i, rel16, cap);
     uint32_t jn[4] = {0u, 0u, 0u, 0u};
-    if (cnt) nbr_load4(rows, row_bytes, off, rel16, i, win_tbl, jn);
+    if (cnt) nbr_load4(nbr_rows_rsrc(rows), row_bytes, off, rel16, i, win_tbl, jn);
     for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
-        const uint32_t j[4] = {jn[0], jn[1], jn[2], jn[3]};
+        const uint32_t jb[4] = {jn[0], jn[1], jn[2], jn[3]};
         float4 xj[4], yj[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            xj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + (j[u] << 4));
-            yj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(y) + (j[u] << 4));
+            xj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + jb[u]);
+            yj[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(y) + jb[u]);
         }
-        rows += 4 * row_bytes;
-        if (k0 + 4 < cnt) nbr_load4(rows, row_bytes, off, rel16, i, win_tbl, jn);
+        rows += 4 * (size_t)row_bytes;
+        if (k0 + 4 < cnt) nbr_load4(nbr_rows_rsrc(rows), row_bytes, off, rel16, i, win_tbl, jn);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (k0 + u < cnt) f(j[u], xj[u], yj[u]);
+            if (k0 + u < cnt) f(jb[u] >> 4, xj[u], yj[u]);
     }
 }
 

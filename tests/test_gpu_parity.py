@@ -614,3 +614,33 @@ def test_snapshot_load_rejects_garbage(tmp_path):
         g.snapshot_load(tmp_path / "bad.pbf")
     with pytest.raises(PbfError):
         g.snapshot_load(tmp_path / "missing.pbf")
+
+
+@pytest.mark.gpu
+def test_addressing_at_the_capacity_limit():
+    """A ctx of 2^28 slots (the largest pbf_create accepts, ~95 GiB) holding a small scene: neighbour rows are
+    1 GiB apart, so the sweeps' buffer loads run with scalar row offsets of up to 3 GiB and the builder's
+    stores reach row k at k GiB.  Bit-identical with the oracle and with a ctx of the scene's own size
+    (tools/check_big_capacity.py is the stand-alone form)."""
+    import torch
+    if torch.cuda.mem_get_info(0)[0] < 120 * 2**30:
+        pytest.skip("needs 120 GiB of free HBM")
+    p, pos, mass, cols = scenes.dam_break(24, 20, 16, iterations=4, max_neighbors=48)
+    pos = np.ascontiguousarray(pos[np.random.default_rng(5).permutation(pos.shape[0])])
+    o = pyoracle.Oracle(p)
+    small = PbfContext(p, device=0)
+    p.capacity = 1 << 28
+    big = PbfContext(p, device=0)
+    for c in (o, small, big):
+        c.upload(pos, uniform_mass=mass)
+        c.set_colliders(cols)
+        for _ in range(4):
+            c.step(DT)
+    bp, bv, _ = big.download()
+    sp, sv, _ = small.download()
+    op, ov = o.download()[:2]
+    assert bp.tobytes() == op.tobytes() and bv.tobytes() == ov.tobytes()
+    assert sp.tobytes() == bp.tobytes() and sv.tobytes() == bv.tobytes()
+    p.capacity = (1 << 28) + 1
+    with pytest.raises(PbfError):
+        PbfContext(p, device=0)

@@ -153,6 +153,7 @@ struct pbf_ctx {
     float *x_rmig[2] = {nullptr, nullptr}, *x_rgh[2] = {nullptr, nullptr};    // in: records
     float4 *x_hsend[2] = {nullptr, nullptr}, *x_hrecv[2] = {nullptr, nullptr};
     uint32_t *x_counts = nullptr;       // device: (1 + world) counter blocks of XC_WORDS: own, then every rank's
+    bool x_counts_clean = false;        // the six split counters of the own block are zero (the last sort cleared them)
     uint32_t *x_host_counts = nullptr;  // pinned host mirror of the same size
     uint32_t *x_hist = nullptr, *x_host_hist = nullptr;   // re-balancing: (1 + world) plane histograms
     uint32_t x_hist_planes = 0;
@@ -345,14 +346,17 @@ int sort_and_neighbors(pbf_ctx* c, bool with_neighbors = true, bool move_vel = t
     {
         PhaseScope ps(c, PH_SORT);
         k_scan_tile_sums<<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums);
+        // an attached slab: this sub-step's split counters have been exchanged and read back by now
+        uint32_t* spent = c->link_comm ? c->x_counts : nullptr;
         if (c->ntiles <= FOLD_MAX_TILES) {
             k_scan_apply<true><<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
-                                                                   c->cell_start, c->cursor, c->flags, crowd);
+                                                                   c->cell_start, c->cursor, c->flags, crowd, spent);
         } else {
             k_scan_sums<<<1, BLOCK, 0, c->stream>>>(c->tile_sums, c->ntiles);
             k_scan_apply<false><<<c->ntiles, BLOCK, 0, c->stream>>>(c->cell_count, c->ncell, c->tile_sums,
-                                                                    c->cell_start, c->cursor, c->flags, crowd);
+                                                                    c->cell_start, c->cursor, c->flags, crowd, spent);
         }
+        if (spent) c->x_counts_clean = true;
         if (n) {
             const int s = c->cur, d = 1 - c->cur;
             const int ps_ = c->prd_cur, pd = (c->prd_cur + 1) % 3;
@@ -424,6 +428,7 @@ void free_link(pbf_ctx* c) {
     (void)hipFree(c->x_counts);
     if (c->x_host_counts) (void)hipHostFree(c->x_host_counts);
     c->x_counts = c->x_host_counts = nullptr;
+    c->x_counts_clean = false;
     (void)hipFree(c->x_hist);
     if (c->x_host_hist) (void)hipHostFree(c->x_host_hist);
     c->x_hist = c->x_host_hist = nullptr;

@@ -20,6 +20,8 @@ def short(n):
 
 names = [short(r[0]) for r in rows]
 pred = [i for i, n in enumerate(names) if n.startswith("k_predict")]
+if len(pred) < 3:   # a slab run: the split pass is the sub-step's first kernel
+    pred = [i for i, n in enumerate(names) if n.startswith("k_slab_split")]
 i0, i1 = pred[-steps - 1], pred[-1]
 print(f"per step on the GPU timeline: {(rows[i1][1] - rows[i0][1]) / steps / 1e3:.1f} us")
 agg = collections.OrderedDict()
